@@ -1,0 +1,115 @@
+"""ctypes binding of the CPU oracle (oracle/libjpegenc_oracle.so).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_SO = os.path.join(_ORACLE_DIR, "libjpegenc_oracle.so")
+
+
+class RefConfig(C.Structure):
+    _fields_ = [("qtab", (C.c_uint16 * 64) * 3),
+                ("quirk_rgb_wrap", C.c_uint8), ("quirk_cb_6d64", C.c_uint8),
+                ("quirk_ydct_zext", C.c_uint8), ("reserved", C.c_uint8)]
+
+
+class RefResult(C.Structure):
+    _fields_ = [("n_full_words", C.c_uint64), ("total_bits_unstuffed", C.c_uint64),
+                ("total_bytes_stuffed", C.c_uint64), ("tail_word", C.c_uint32),
+                ("tail_bits", C.c_uint8), ("eof_partial_ready", C.c_uint8), ("pad", C.c_uint8 * 2)]
+
+
+def build(force=False):
+    src = os.path.join(_ORACLE_DIR, "jpegenc_ref.cpp")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _ORACLE_DIR, "libjpegenc_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        L.ref_default_config.argtypes = [C.POINTER(RefConfig)]
+        L.ref_rgb2ycbcr_px.argtypes = [C.POINTER(RefConfig), C.c_uint32, C.POINTER(C.c_uint8)]
+        L.ref_dct8x8.argtypes = [C.POINTER(RefConfig), C.c_void_p, C.c_int, C.c_void_p]
+        L.ref_quantize.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_block_coeffs.argtypes = [C.POINTER(RefConfig), C.c_int, C.c_void_p, C.c_void_p]
+        L.ref_huff_block.argtypes = [C.POINTER(RefConfig), C.c_int, C.c_void_p, C.POINTER(C.c_int32),
+                                     C.c_void_p, C.c_size_t]
+        L.ref_huff_block.restype = C.c_long
+        L.ref_max_words.argtypes = [C.c_int, C.c_int]
+        L.ref_max_words.restype = C.c_size_t
+        L.ref_encode_rgb8.argtypes = [C.POINTER(RefConfig), C.c_void_p, C.c_int, C.c_int, C.c_ssize_t,
+                                      C.c_void_p, C.c_size_t, C.POINTER(RefResult)]
+        L.ref_encode_rgb8_unstuffed.argtypes = [C.POINTER(RefConfig), C.c_void_p, C.c_int, C.c_int, C.c_ssize_t,
+                                                C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
+        L.ref_image_coeffs.argtypes = [C.POINTER(RefConfig), C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_void_p]
+        L.ref_port_open.argtypes = [C.POINTER(RefConfig)]
+        L.ref_port_open.restype = C.c_void_p
+        L.ref_port_reset.argtypes = [C.c_void_p]
+        L.ref_port_push_pixel.argtypes = [C.c_void_p, C.c_uint32]
+        L.ref_port_end_of_file.argtypes = [C.c_void_p, C.POINTER(RefResult)]
+        L.ref_port_end_of_file.restype = C.c_size_t
+        L.ref_port_words.argtypes = [C.c_void_p]
+        L.ref_port_words.restype = C.POINTER(C.c_uint32)
+        L.ref_port_close.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def default_config(qtabs=None, rgb_wrap=True, cb_6d64=True, ydct_zext=False):
+    cfg = RefConfig()
+    lib().ref_default_config(C.byref(cfg))
+    if qtabs is not None:
+        for c in range(3):
+            for i in range(64):
+                cfg.qtab[c][i] = int(qtabs[c][i])
+    cfg.quirk_rgb_wrap = int(rgb_wrap)
+    cfg.quirk_cb_6d64 = int(cb_6d64)
+    cfg.quirk_ydct_zext = int(ydct_zext)
+    return cfg
+
+
+def encode(rgb, cfg=None):
+    """rgb: (h,w,3) uint8 C-contiguous.  Returns (words uint32 array incl. tail word, RefResult)."""
+    cfg = cfg or default_config()
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w, _ = rgb.shape
+    cap = lib().ref_max_words(w, h)
+    words = np.zeros(cap, dtype=np.uint32)
+    res = RefResult()
+    rc = lib().ref_encode_rgb8(C.byref(cfg), rgb.ctypes.data, w, h, w * 3, words.ctypes.data, cap, C.byref(res))
+    if rc:
+        raise RuntimeError("ref_encode_rgb8 rc=%d" % rc)
+    n = res.n_full_words + (1 if res.tail_bits else 0)
+    return words[:n].copy(), res
+
+
+def image_coeffs(rgb, cfg=None):
+    cfg = cfg or default_config()
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w, _ = rgb.shape
+    out = np.zeros(((h // 8) * (w // 8), 3, 64), dtype=np.int16)
+    rc = lib().ref_image_coeffs(C.byref(cfg), rgb.ctypes.data, w, h, w * 3, out.ctypes.data)
+    if rc:
+        raise RuntimeError("ref_image_coeffs rc=%d" % rc)
+    return out
+
+
+def huff_block(blk_huff_order, comp, pred=0, cfg=None):
+    """blk_huff_order: 64 ints, index a*8+b (a vertical).  Returns (bit string, new pred)."""
+    cfg = cfg or default_config()
+    blk = np.asarray(blk_huff_order, dtype=np.int32).copy()
+    bits = np.zeros(4096, dtype=np.uint8)
+    p = C.c_int32(pred)
+    n = lib().ref_huff_block(C.byref(cfg), comp, blk.ctypes.data, C.byref(p), bits.ctypes.data, bits.size)
+    assert n >= 0
+    return "".join(str(int(b)) for b in bits[:n]), p.value
