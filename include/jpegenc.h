@@ -1,0 +1,150 @@
+/* jpegenc.h -- C ABI of libjpegenc.so: the jpeg_top data path on MI355X (gfx950).
+ *
+ * The reference design's only interface is the port list of its top module
+ *   rtl/0_jpeg_top/jpeg_top.sv:18-28
+ *     clk, rst, end_of_file_signal, enable, data_in[23:0]
+ *     -> JPEG_bitstream[31:0], data_ready, end_of_file_bitstream_count[4:0], eof_data_partial_ready
+ * Each entry point below names the port(s) it stands for.  The library is the GPU path only:
+ * there is no CPU fallback, and every compute entry point fails with JPEGENC_E_HIP when no
+ * gfx950 device is usable.
+ *
+ * Stream format (identical to what jpeg_top presents on JPEG_bitstream): for every 8x8 block in
+ * feed order the Huffman bits of Y, Cb, Cr; MSB first; 0x00 stuffed after every complete 0xFF byte;
+ * cut into 32-bit words whose bit 31 is the first bit.  No JPEG markers.  The residual bits after
+ * the last full word are reported left-aligned in `tail_word` with their count in `tail_bits`.
+ *
+ * Threading: a context is bound to one device and one stream and is not thread-safe; distinct
+ * contexts are independent.  All calls return 0 or a negative JPEGENC_E_* code; nothing throws.
+ */
+#ifndef JPEGENC_H
+#define JPEGENC_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JPEGENC_OK 0
+#define JPEGENC_E_BAD_ARG (-1)   /* null pointer, w/h not positive multiples of 8, bad stride */
+#define JPEGENC_E_TOO_SMALL (-2) /* output capacity too small; result reports the size needed */
+#define JPEGENC_E_HIP (-3)       /* HIP runtime error or no usable GPU; see jpegenc_last_error */
+#define JPEGENC_E_UNSUPPORTED (-4)
+#define JPEGENC_E_NOMEM (-5)
+#define JPEGENC_E_STATE (-6) /* push/end_of_file protocol misuse */
+
+/* flags for the encode calls */
+#define JPEGENC_HOST_PTRS 0u   /* rgb / words_out / results are host memory (copied, call blocks) */
+#define JPEGENC_DEVICE_PTRS 1u /* all three are device memory on the context's device; the call
+                                  only enqueues work on the context's stream */
+
+typedef struct jpegenc_ctx jpegenc_ctx;
+
+/* Configuration = the SystemVerilog parameters of the design plus the as-written/repaired
+ * switches for the arithmetic accidents in the RTL text. */
+typedef struct jpegenc_config {
+    /* Y_Q_MATRIX / CB_Q_MATRIX / CR_Q_MATRIX (rtl/3_quantization/y_quantizer.sv:15-17,
+     * cb_quantizer.sv:19-21, cr_quantizer.sv:11-13).  Entry [i*8+j] scales DCT output Z{i+1}{j+1}
+     * (i = horizontal frequency).  Default: all ones. */
+    uint16_t qtab[3][64];
+    uint8_t quirk_rgb_wrap;  /* 1 = 8-bit wrap in the colour rounder as written (rgb2ycrcb.sv:105-113) */
+    uint8_t quirk_cb_6d64;   /* 1 = cb_huff's 6'd64 literal as written (cb_huff.sv:238,241) */
+    uint8_t quirk_ydct_zext; /* must be 0: the luma zero-extension accident (y_dct.sv:65-66,171-177)
+                                is repaired; 1 is rejected with JPEGENC_E_UNSUPPORTED */
+    uint8_t reserved;
+    int32_t device;          /* HIP device ordinal */
+} jpegenc_config;
+
+/* What jpeg_top signals at end of file, per image (jpeg_top.sv:24-27), plus sizes. */
+typedef struct jpegenc_result {
+    uint64_t n_full_words;         /* number of data_ready pulses: complete 32-bit words */
+    uint64_t total_bits_unstuffed; /* Huffman bits before stuffing */
+    uint64_t total_bytes_stuffed;  /* complete bytes after stuffing */
+    uint32_t tail_word;            /* JPEG_bitstream at eof_data_partial_ready: residual, left-aligned */
+    uint8_t tail_bits;             /* end_of_file_bitstream_count[4:0] */
+    uint8_t eof_partial_ready;     /* eof_data_partial_ready (tail_bits != 0) */
+    int16_t status;                /* JPEGENC_OK or JPEGENC_E_TOO_SMALL for this image */
+} jpegenc_result;
+
+/* Fills cfg with the RTL defaults (all-ones tables, quirks as written, device 0). */
+int jpegenc_default_config(jpegenc_config* cfg);
+
+/* Creates a context on cfg->device with its own stream.  Stands for instantiating jpeg_top. */
+int jpegenc_create(jpegenc_ctx** out, const jpegenc_config* cfg);
+int jpegenc_destroy(jpegenc_ctx* ctx);
+
+/* Makes the context launch on a caller-owned hipStream_t (pass NULL to go back to its own). */
+int jpegenc_set_stream(jpegenc_ctx* ctx, void* hip_stream);
+/* Blocks until everything enqueued by this context has finished. */
+int jpegenc_synchronize(jpegenc_ctx* ctx);
+
+/* Upper bound on words (full words + tail word) for a w x h image:
+ * <= 22 + 63*26 bits per component block, doubled for stuffing. */
+size_t jpegenc_max_words(int w, int h);
+
+/* One image.  Replaces: rst, then `enable` with one pixel per clock on data_in[23:0] =
+ * {B,G,R} (rgb2ycrcb.sv:21) for every 8x8 block left->right, top->bottom, then
+ * end_of_file_signal (jpeg_top.sv:20-23).  `rgb` is a raster of R,G,B bytes, `stride` bytes per
+ * row; w and h must be multiples of 8 (the design has no edge handling: a block is 64 consecutive
+ * samples, cb_dct.sv:478-541).  words_out receives the JPEG_bitstream words in data_ready order,
+ * followed by the tail word when tail_bits != 0 (jpeg_top.sv:24-27). */
+int jpegenc_encode_rgb8(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int h, ptrdiff_t stride, uint32_t flags,
+                        uint32_t* words_out, size_t cap_words, jpegenc_result* result);
+
+/* n independent images of equal size (each starts from rst).  Image i starts at
+ * rgb + i*image_stride and writes to words_out + i*cap_words_per_image; results[i] is filled.
+ * An image whose stream does not fit gets status JPEGENC_E_TOO_SMALL (sizes still reported, no
+ * write beyond its slot) and the call returns JPEGENC_E_TOO_SMALL after finishing the others
+ * (host-pointer mode) or JPEGENC_OK (device-pointer mode: check results[i].status). */
+int jpegenc_encode_batch(jpegenc_ctx* ctx, const uint8_t* rgb, int n_images, int w, int h, ptrdiff_t stride,
+                         ptrdiff_t image_stride, uint32_t flags, uint32_t* words_out, size_t cap_words_per_image,
+                         jpegenc_result* results);
+
+/* One image cut into n_stripes horizontal stripes of stripe_rows rows (a multiple of 8;
+ * n_stripes*stripe_rows == h).  Every stripe is encoded exactly as jpeg_top would encode that
+ * w x stripe_rows sub-image after rst -- the restart-interval view of a huge image.  Equivalent to
+ * jpegenc_encode_batch with image_stride = stripe_rows*stride. */
+int jpegenc_encode_stripes(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int h, ptrdiff_t stride, int n_stripes,
+                           uint32_t flags, uint32_t* words_out, size_t cap_words_per_stripe,
+                           jpegenc_result* results);
+
+/* Port-level protocol, one call per clock edge of interest (jpeg_top.sv:20-27):
+ *   jpegenc_reset        = rst
+ *   jpegenc_push_pixel   = enable with data_in[23:0] = {B[23:16],G[15:8],R[7:0]}; 64 consecutive
+ *                          pixels are one 8x8 block, row-major
+ *   jpegenc_end_of_file  = end_of_file_signal: runs the GPU path over the pushed blocks
+ *   jpegenc_read_words   = the JPEG_bitstream words in data_ready order (+ tail word)
+ * Pixels are staged on the host and encoded on the device at end_of_file. */
+int jpegenc_reset(jpegenc_ctx* ctx);
+int jpegenc_push_pixel(jpegenc_ctx* ctx, uint32_t data_in24);
+int jpegenc_push_pixels(jpegenc_ctx* ctx, const uint32_t* data_in24, size_t n);
+int jpegenc_end_of_file(jpegenc_ctx* ctx, jpegenc_result* result);
+int jpegenc_read_words(jpegenc_ctx* ctx, uint32_t* words_out, size_t cap_words, size_t* n_words);
+
+/* Helper: words (value semantics, bit 31 first) -> byte stream; writes ceil(nbits/8) bytes where
+ * nbits = 32*n_full_words + tail_bits.  Host memory only. */
+int jpegenc_words_to_bytes(const uint32_t* words, const jpegenc_result* result, uint8_t* bytes_out, size_t cap_bytes,
+                           size_t* n_bytes);
+
+/* Optional per-kernel timing with HIP events on the context's stream.  When enabled every kernel
+ * launch is bracketed by events; jpegenc_kernel_times returns, per kernel, the number of launches
+ * and the summed duration in ms since the last reset (this call synchronises the stream). */
+#define JPEGENC_N_KERNELS 4
+int jpegenc_set_profiling(jpegenc_ctx* ctx, int enable);
+int jpegenc_kernel_times(jpegenc_ctx* ctx, uint64_t launches[JPEGENC_N_KERNELS], double ms[JPEGENC_N_KERNELS],
+                         int reset);
+const char* jpegenc_kernel_name(int index);
+
+/* Scratch memory budget in bytes for the intermediate chunk streams (default 4 GiB); a batch is
+ * processed in sub-batches that fit. */
+int jpegenc_set_workspace_limit(jpegenc_ctx* ctx, size_t bytes);
+
+const char* jpegenc_strerror(int code);
+/* Text of the last HIP error seen by this context ("" if none). */
+const char* jpegenc_last_error(const jpegenc_ctx* ctx);
+const char* jpegenc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JPEGENC_H */

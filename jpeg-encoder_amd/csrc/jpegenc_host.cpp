@@ -1,0 +1,537 @@
+// jpegenc_host.cpp -- C ABI of libjpegenc.so (include/jpegenc.h): context, workspace, launch sequencing.
+// The compute path is the HIP kernels in jpegenc_kernels.hip; there is no CPU fallback in this library.
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "jpegenc_internal.h"
+#include "jpegenc_tables.h"
+
+using namespace jpegenc;
+
+namespace jpegenc {
+
+// entry = ((code << size) << 5) | (code_length + size); index (run<<4|size) for AC, 256+size for DC.
+// Code/length tables: T.81 K.4 (DC) and K.5 (AC) as hard-coded in rtl/4_huffman/cr_huff.sv:1553-2082.
+void build_htab(uint32_t out[kHtabEntries]) {
+    for (int i = 0; i < kHtabEntries; ++i) out[i] = 0;
+    for (int sym = 0; sym < 256; ++sym) {
+        const int idx = JPEGENC_AC_RUN_CODE[sym];
+        const int size = sym & 15;
+        if (idx == 0xFF || size > 10) continue;
+        const uint32_t code = JPEGENC_AC_CODE[idx];
+        const uint32_t len = JPEGENC_AC_LEN[idx];
+        out[sym] = ((code << size) << 5) | (len + size);
+    }
+    for (int s = 0; s < 12; ++s) {
+        const uint32_t code = JPEGENC_DC_CODE[s];
+        const uint32_t len = JPEGENC_DC_LEN[s];
+        out[kHtabDc + s] = ((code << s) << 5) | (len + s);
+    }
+}
+
+}  // namespace jpegenc
+
+namespace {
+
+enum KernelId { K_ENCODE = 0, K_SCAN = 1, K_STUFF_COUNT = 2, K_STUFF_WRITE = 3 };
+const char* const kKernelNames[JPEGENC_N_KERNELS] = {"k_encode_chunks", "k_scan", "k_stuff_count", "k_stuff_write"};
+
+struct EventPair {
+    int kernel;
+    hipEvent_t a, b;
+};
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;  // elements
+    hipError_t reserve(size_t want) {
+        if (want <= n) return hipSuccess;
+        if (p) {
+            hipError_t e = hipFree(p);
+            p = nullptr;
+            n = 0;
+            if (e != hipSuccess) return e;
+        }
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
+        if (e == hipSuccess) n = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+}  // namespace
+
+struct jpegenc_ctx {
+    jpegenc_config cfg;
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    size_t ws_limit = size_t(4) << 30;
+    bool quant = false;
+    uint32_t flags = 0;
+
+    DevBuf<uint32_t> htab;
+    DevBuf<int32_t> qmul;
+    // workspace, sized for ws_chunks chunks
+    DevBuf<uint32_t> slots;
+    DevBuf<uint32_t> chunk_bits, chunk_ff;
+    DevBuf<uint64_t> bit_off, ff_off;
+    // staging for host-pointer calls
+    DevBuf<uint8_t> in_stage;
+    DevBuf<uint32_t> out_stage;
+    DevBuf<jpegenc_result> res_stage;
+
+    // port-level protocol
+    std::vector<uint8_t> port_px;
+    std::vector<uint32_t> port_words;
+    bool port_done = false;
+
+    bool profiling = false;
+    std::vector<EventPair> events;
+    uint64_t k_launches[JPEGENC_N_KERNELS] = {0, 0, 0, 0};
+    double k_ms[JPEGENC_N_KERNELS] = {0, 0, 0, 0};
+
+    std::string last_error;
+};
+
+namespace {
+
+int fail_hip(jpegenc_ctx* ctx, hipError_t e, const char* what) {
+    if (ctx) {
+        char buf[256];
+        std::snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+        ctx->last_error = buf;
+    }
+    return JPEGENC_E_HIP;
+}
+
+#define HIPCHK(ctx, expr)                                       \
+    do {                                                        \
+        hipError_t e_ = (expr);                                 \
+        if (e_ != hipSuccess) return fail_hip(ctx, e_, #expr);  \
+    } while (0)
+
+struct ProfScope {
+    jpegenc_ctx* ctx;
+    EventPair ep;
+    bool on;
+    ProfScope(jpegenc_ctx* c, int kernel) : ctx(c), on(c->profiling) {
+        if (!on) return;
+        ep.kernel = kernel;
+        if (hipEventCreate(&ep.a) != hipSuccess || hipEventCreate(&ep.b) != hipSuccess) {
+            on = false;
+            return;
+        }
+        (void)hipEventRecord(ep.a, ctx->stream);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(ep.b, ctx->stream);
+        ctx->events.push_back(ep);
+    }
+};
+
+int pointer_align(const void* p, int64_t stride, int64_t image_stride, int n_images) {
+    uint64_t bits = reinterpret_cast<uintptr_t>(p) | uint64_t(stride);
+    if (n_images > 1) bits |= uint64_t(image_stride);
+    if ((bits & 7) == 0) return 8;
+    if ((bits & 3) == 0) return 4;
+    return 1;
+}
+
+// All pointers are device memory.  Enqueues the whole pipeline on ctx->stream.
+int encode_device(jpegenc_ctx* ctx, const uint8_t* rgb, int n_images, int w, int h, ptrdiff_t stride,
+                  ptrdiff_t image_stride, uint32_t* words, size_t cap_words, jpegenc_result* results) {
+    const uint32_t mcu_w = uint32_t(w / 8), mcu_h = uint32_t(h / 8);
+    const uint64_t n_mcu64 = uint64_t(mcu_w) * mcu_h;
+    if (n_mcu64 > 0x7FFFFFFFull) return JPEGENC_E_UNSUPPORTED;
+    const uint32_t n_mcu = uint32_t(n_mcu64);
+    const uint32_t cpi = (n_mcu + kChunkMcus - 1) / kChunkMcus;
+    const size_t slot_bytes = size_t(kSlotWords) * 4;
+
+    // sub-batch size: as many images as fit the workspace budget (at least one)
+    uint64_t per_image = uint64_t(cpi) * slot_bytes;
+    uint32_t sub = uint32_t(ctx->ws_limit / (per_image ? per_image : 1));
+    if (sub < 1) sub = 1;
+    if (sub > uint32_t(n_images)) sub = uint32_t(n_images);
+    while (uint64_t(sub) * cpi > 0x7FFFFFF0ull) sub /= 2;  // grid limit
+    const size_t ws_chunks = size_t(sub) * cpi;
+
+    HIPCHK(ctx, ctx->slots.reserve((ws_chunks + 1) * size_t(kSlotWords)));
+    HIPCHK(ctx, ctx->chunk_bits.reserve(ws_chunks));
+    HIPCHK(ctx, ctx->chunk_ff.reserve(ws_chunks));
+    HIPCHK(ctx, ctx->bit_off.reserve(ws_chunks));
+    HIPCHK(ctx, ctx->ff_off.reserve(ws_chunks));
+
+    const int align = pointer_align(rgb, stride, image_stride, n_images);
+
+    for (int first = 0; first < n_images; first += int(sub)) {
+        const uint32_t n = uint32_t(std::min<int64_t>(sub, n_images - first));
+        EncodeParams ep;
+        ep.rgb = rgb + int64_t(first) * image_stride;
+        ep.stride = stride;
+        ep.image_stride = image_stride;
+        ep.mcu_w = mcu_w;
+        ep.n_mcu = n_mcu;
+        ep.cpi = cpi;
+        ep.flags = ctx->flags;
+        ep.slots = ctx->slots.p;
+        ep.chunk_bits = ctx->chunk_bits.p;
+        ep.htab = ctx->htab.p;
+        ep.qmul = ctx->quant ? ctx->qmul.p : nullptr;
+        {
+            ProfScope ps(ctx, K_ENCODE);
+            HIPCHK(ctx, launch_encode(ep, n, align, ctx->stream));
+        }
+        ScanParams sp;
+        sp.counts = ctx->chunk_bits.p;
+        sp.prefix = ctx->bit_off.p;
+        sp.cpi = cpi;
+        {
+            ProfScope ps(ctx, K_SCAN);
+            HIPCHK(ctx, launch_scan(sp, n, ctx->stream));
+        }
+        StuffParams tp;
+        tp.slots = ctx->slots.p;
+        tp.chunk_bits = ctx->chunk_bits.p;
+        tp.bit_off = ctx->bit_off.p;
+        tp.chunk_ff = ctx->chunk_ff.p;
+        tp.ff_off = ctx->ff_off.p;
+        tp.words_out = words + uint64_t(first) * cap_words;
+        tp.out_stride = cap_words;
+        tp.cap_words = cap_words;
+        tp.results = results + first;
+        tp.cpi = cpi;
+        {
+            ProfScope ps(ctx, K_STUFF_COUNT);
+            HIPCHK(ctx, launch_stuff_count(tp, n, ctx->stream));
+        }
+        sp.counts = ctx->chunk_ff.p;
+        sp.prefix = ctx->ff_off.p;
+        {
+            ProfScope ps(ctx, K_SCAN);
+            HIPCHK(ctx, launch_scan(sp, n, ctx->stream));
+        }
+        {
+            ProfScope ps(ctx, K_STUFF_WRITE);
+            HIPCHK(ctx, launch_stuff_write(tp, n, ctx->stream));
+        }
+    }
+    return JPEGENC_OK;
+}
+
+int check_dims(const void* rgb, int n, int w, int h, ptrdiff_t stride, const void* words, const void* results) {
+    if (!rgb || !words || !results) return JPEGENC_E_BAD_ARG;
+    if (n <= 0 || w <= 0 || h <= 0 || (w % 8) || (h % 8)) return JPEGENC_E_BAD_ARG;
+    if (stride < ptrdiff_t(w) * 3) return JPEGENC_E_BAD_ARG;
+    return JPEGENC_OK;
+}
+
+int encode_host(jpegenc_ctx* ctx, const uint8_t* rgb, int n_images, int w, int h, ptrdiff_t stride,
+                ptrdiff_t image_stride, uint32_t* words, size_t cap_words, jpegenc_result* results) {
+    const size_t row = size_t(w) * 3;
+    const size_t img_bytes = row * size_t(h);
+    HIPCHK(ctx, ctx->in_stage.reserve(img_bytes * size_t(n_images)));
+    HIPCHK(ctx, ctx->out_stage.reserve(cap_words * size_t(n_images)));
+    HIPCHK(ctx, ctx->res_stage.reserve(size_t(n_images)));
+    for (int i = 0; i < n_images; ++i)
+        HIPCHK(ctx, hipMemcpy2DAsync(ctx->in_stage.p + img_bytes * size_t(i), row, rgb + int64_t(i) * image_stride,
+                                     size_t(stride), row, size_t(h), hipMemcpyHostToDevice, ctx->stream));
+    int rc = encode_device(ctx, ctx->in_stage.p, n_images, w, h, ptrdiff_t(row), ptrdiff_t(img_bytes),
+                           ctx->out_stage.p, cap_words, ctx->res_stage.p);
+    if (rc != JPEGENC_OK) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(results, ctx->res_stage.p, sizeof(jpegenc_result) * size_t(n_images),
+                               hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n_images; ++i) {
+        uint64_t nw = results[i].n_full_words + (results[i].tail_bits ? 1 : 0);
+        if (nw > cap_words) {
+            nw = cap_words;
+            rc = JPEGENC_E_TOO_SMALL;
+        }
+        if (nw)
+            HIPCHK(ctx, hipMemcpyAsync(words + size_t(i) * cap_words, ctx->out_stage.p + size_t(i) * cap_words,
+                                       size_t(nw) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int jpegenc_default_config(jpegenc_config* cfg) {
+    if (!cfg) return JPEGENC_E_BAD_ARG;
+    std::memset(cfg, 0, sizeof *cfg);
+    for (int c = 0; c < 3; ++c)
+        for (int i = 0; i < 64; ++i) cfg->qtab[c][i] = 1;
+    cfg->quirk_rgb_wrap = 1;
+    cfg->quirk_cb_6d64 = 1;
+    cfg->quirk_ydct_zext = 0;
+    cfg->device = 0;
+    return JPEGENC_OK;
+}
+
+int jpegenc_create(jpegenc_ctx** out, const jpegenc_config* cfg) {
+    if (!out || !cfg) return JPEGENC_E_BAD_ARG;
+    *out = nullptr;
+    if (cfg->quirk_ydct_zext) return JPEGENC_E_UNSUPPORTED;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return JPEGENC_E_HIP;
+    if (cfg->device < 0 || cfg->device >= ndev) return JPEGENC_E_BAD_ARG;
+    jpegenc_ctx* ctx = new (std::nothrow) jpegenc_ctx;
+    if (!ctx) return JPEGENC_E_NOMEM;
+    ctx->cfg = *cfg;
+    ctx->device = cfg->device;
+    hipError_t e = hipSetDevice(ctx->device);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, ctx->device);
+    if (e == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        delete ctx;
+        return JPEGENC_E_HIP;  // the code object is gfx950-only
+    }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        return JPEGENC_E_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    ctx->flags = (cfg->quirk_rgb_wrap ? 1u : 0u) | (cfg->quirk_cb_6d64 ? 2u : 0u);
+
+    uint32_t htab[kHtabEntries];
+    build_htab(htab);
+    int32_t qmul[3 * 64];
+    bool all_ones = true;
+    for (int c = 0; c < 3; ++c)
+        for (int a = 0; a < 8; ++a)
+            for (int b = 0; b < 8; ++b) {
+                // Huffman-input position (a vertical, b horizontal) is DCT output Z{b+1}{a+1}, which the
+                // quantiser scales with table entry [b*8+a] (y_quantizer.sv:40-43, yd_q_h.sv:120-135).
+                const uint16_t q = cfg->qtab[c][b * 8 + a];
+                if (q != 1) all_ones = false;
+                qmul[c * 64 + a * 8 + b] = q ? int32_t(4096 / q) : 0;
+            }
+    ctx->quant = !all_ones;
+    e = ctx->htab.reserve(kHtabEntries);
+    if (e == hipSuccess) e = ctx->qmul.reserve(3 * 64);
+    if (e == hipSuccess) e = hipMemcpy(ctx->htab.p, htab, sizeof htab, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(ctx->qmul.p, qmul, sizeof qmul, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        jpegenc_destroy(ctx);
+        return JPEGENC_E_HIP;
+    }
+    *out = ctx;
+    return JPEGENC_OK;
+}
+
+int jpegenc_destroy(jpegenc_ctx* ctx) {
+    if (!ctx) return JPEGENC_E_BAD_ARG;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto& ep : ctx->events) {
+        (void)hipEventDestroy(ep.a);
+        (void)hipEventDestroy(ep.b);
+    }
+    ctx->htab.release();
+    ctx->qmul.release();
+    ctx->slots.release();
+    ctx->chunk_bits.release();
+    ctx->chunk_ff.release();
+    ctx->bit_off.release();
+    ctx->ff_off.release();
+    ctx->in_stage.release();
+    ctx->out_stage.release();
+    ctx->res_stage.release();
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return JPEGENC_OK;
+}
+
+int jpegenc_set_stream(jpegenc_ctx* ctx, void* hip_stream) {
+    if (!ctx) return JPEGENC_E_BAD_ARG;
+    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return JPEGENC_OK;
+}
+
+int jpegenc_synchronize(jpegenc_ctx* ctx) {
+    if (!ctx) return JPEGENC_E_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return JPEGENC_OK;
+}
+
+size_t jpegenc_max_words(int w, int h) {
+    if (w <= 0 || h <= 0) return 0;
+    const uint64_t mcus = uint64_t(w / 8) * uint64_t(h / 8);
+    return size_t((mcus * uint64_t(kMaxMcuBits) * 2 + 31) / 32 + 1);
+}
+
+int jpegenc_encode_batch(jpegenc_ctx* ctx, const uint8_t* rgb, int n_images, int w, int h, ptrdiff_t stride,
+                         ptrdiff_t image_stride, uint32_t flags, uint32_t* words_out, size_t cap_words_per_image,
+                         jpegenc_result* results) {
+    if (!ctx) return JPEGENC_E_BAD_ARG;
+    int rc = check_dims(rgb, n_images, w, h, stride, words_out, results);
+    if (rc != JPEGENC_OK) return rc;
+    if (cap_words_per_image == 0) return JPEGENC_E_BAD_ARG;
+    if (n_images > 1 && (image_stride < 0 ? -image_stride : image_stride) < stride * ptrdiff_t(h) && image_stride != 0)
+        return JPEGENC_E_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (flags & JPEGENC_DEVICE_PTRS)
+        return encode_device(ctx, rgb, n_images, w, h, stride, image_stride, words_out, cap_words_per_image, results);
+    return encode_host(ctx, rgb, n_images, w, h, stride, image_stride, words_out, cap_words_per_image, results);
+}
+
+int jpegenc_encode_rgb8(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int h, ptrdiff_t stride, uint32_t flags,
+                        uint32_t* words_out, size_t cap_words, jpegenc_result* result) {
+    return jpegenc_encode_batch(ctx, rgb, 1, w, h, stride, stride * ptrdiff_t(h), flags, words_out, cap_words, result);
+}
+
+int jpegenc_encode_stripes(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int h, ptrdiff_t stride, int n_stripes,
+                           uint32_t flags, uint32_t* words_out, size_t cap_words_per_stripe,
+                           jpegenc_result* results) {
+    if (n_stripes <= 0 || h <= 0 || (h % n_stripes)) return JPEGENC_E_BAD_ARG;
+    const int rows = h / n_stripes;
+    if (rows % 8) return JPEGENC_E_BAD_ARG;
+    return jpegenc_encode_batch(ctx, rgb, n_stripes, w, rows, stride, stride * ptrdiff_t(rows), flags, words_out,
+                                cap_words_per_stripe, results);
+}
+
+int jpegenc_reset(jpegenc_ctx* ctx) {
+    if (!ctx) return JPEGENC_E_BAD_ARG;
+    ctx->port_px.clear();
+    ctx->port_words.clear();
+    ctx->port_done = false;
+    return JPEGENC_OK;
+}
+
+int jpegenc_push_pixel(jpegenc_ctx* ctx, uint32_t d) {
+    if (!ctx) return JPEGENC_E_BAD_ARG;
+    if (ctx->port_done) return JPEGENC_E_STATE;  // rst is required after end_of_file
+    ctx->port_px.push_back(uint8_t(d & 0xFF));          // R = data_in[7:0]
+    ctx->port_px.push_back(uint8_t((d >> 8) & 0xFF));   // G = data_in[15:8]
+    ctx->port_px.push_back(uint8_t((d >> 16) & 0xFF));  // B = data_in[23:16]
+    return JPEGENC_OK;
+}
+
+int jpegenc_push_pixels(jpegenc_ctx* ctx, const uint32_t* d, size_t n) {
+    if (!ctx || (!d && n)) return JPEGENC_E_BAD_ARG;
+    if (ctx->port_done) return JPEGENC_E_STATE;
+    ctx->port_px.reserve(ctx->port_px.size() + n * 3);
+    for (size_t i = 0; i < n; ++i) {
+        ctx->port_px.push_back(uint8_t(d[i] & 0xFF));
+        ctx->port_px.push_back(uint8_t((d[i] >> 8) & 0xFF));
+        ctx->port_px.push_back(uint8_t((d[i] >> 16) & 0xFF));
+    }
+    return JPEGENC_OK;
+}
+
+int jpegenc_end_of_file(jpegenc_ctx* ctx, jpegenc_result* result) {
+    if (!ctx || !result) return JPEGENC_E_BAD_ARG;
+    if (ctx->port_done) return JPEGENC_E_STATE;
+    // 64 consecutive samples are one block, row-major (cb_dct.sv:478-541): the pushed stream is a
+    // raster image 8 pixels wide.  A trailing partial block never completes a DCT and is dropped.
+    const size_t nblk = ctx->port_px.size() / (64 * 3);
+    std::memset(result, 0, sizeof *result);
+    ctx->port_words.clear();
+    ctx->port_done = true;
+    if (nblk == 0) return JPEGENC_OK;
+    if (nblk > size_t(0x7FFFFFFF) / 8) return JPEGENC_E_UNSUPPORTED;
+    const int h = int(nblk * 8);
+    ctx->port_words.assign(jpegenc_max_words(8, h), 0);
+    int rc = jpegenc_encode_rgb8(ctx, ctx->port_px.data(), 8, h, 24, JPEGENC_HOST_PTRS, ctx->port_words.data(),
+                                 ctx->port_words.size(), result);
+    if (rc != JPEGENC_OK) return rc;
+    ctx->port_words.resize(size_t(result->n_full_words) + (result->tail_bits ? 1 : 0));
+    ctx->port_px.clear();
+    return JPEGENC_OK;
+}
+
+int jpegenc_read_words(jpegenc_ctx* ctx, uint32_t* words_out, size_t cap_words, size_t* n_words) {
+    if (!ctx || !n_words) return JPEGENC_E_BAD_ARG;
+    if (!ctx->port_done) return JPEGENC_E_STATE;
+    *n_words = ctx->port_words.size();
+    if (cap_words < ctx->port_words.size() || (!words_out && !ctx->port_words.empty())) return JPEGENC_E_TOO_SMALL;
+    if (!ctx->port_words.empty()) std::memcpy(words_out, ctx->port_words.data(), ctx->port_words.size() * 4);
+    return JPEGENC_OK;
+}
+
+int jpegenc_words_to_bytes(const uint32_t* words, const jpegenc_result* r, uint8_t* bytes_out, size_t cap_bytes,
+                           size_t* n_bytes) {
+    if (!words || !r || !n_bytes) return JPEGENC_E_BAD_ARG;
+    const uint64_t nbits = r->n_full_words * 32 + r->tail_bits;
+    const size_t nb = size_t((nbits + 7) / 8);
+    *n_bytes = nb;
+    if (nb > cap_bytes || (!bytes_out && nb)) return JPEGENC_E_TOO_SMALL;
+    for (size_t i = 0; i < nb; ++i) bytes_out[i] = uint8_t(words[i >> 2] >> (24 - 8 * (i & 3)));
+    return JPEGENC_OK;
+}
+
+int jpegenc_set_profiling(jpegenc_ctx* ctx, int enable) {
+    if (!ctx) return JPEGENC_E_BAD_ARG;
+    ctx->profiling = enable != 0;
+    return JPEGENC_OK;
+}
+
+int jpegenc_kernel_times(jpegenc_ctx* ctx, uint64_t launches[JPEGENC_N_KERNELS], double ms[JPEGENC_N_KERNELS],
+                         int reset) {
+    if (!ctx || !launches || !ms) return JPEGENC_E_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& ep : ctx->events) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, ep.a, ep.b) == hipSuccess) {
+            ctx->k_launches[ep.kernel] += 1;
+            ctx->k_ms[ep.kernel] += double(t);
+        }
+        (void)hipEventDestroy(ep.a);
+        (void)hipEventDestroy(ep.b);
+    }
+    ctx->events.clear();
+    for (int i = 0; i < JPEGENC_N_KERNELS; ++i) {
+        launches[i] = ctx->k_launches[i];
+        ms[i] = ctx->k_ms[i];
+        if (reset) {
+            ctx->k_launches[i] = 0;
+            ctx->k_ms[i] = 0;
+        }
+    }
+    return JPEGENC_OK;
+}
+
+const char* jpegenc_kernel_name(int index) {
+    return (index >= 0 && index < JPEGENC_N_KERNELS) ? kKernelNames[index] : "";
+}
+
+int jpegenc_set_workspace_limit(jpegenc_ctx* ctx, size_t bytes) {
+    if (!ctx || bytes == 0) return JPEGENC_E_BAD_ARG;
+    ctx->ws_limit = bytes;
+    return JPEGENC_OK;
+}
+
+const char* jpegenc_strerror(int code) {
+    switch (code) {
+        case JPEGENC_OK: return "ok";
+        case JPEGENC_E_BAD_ARG: return "bad argument";
+        case JPEGENC_E_TOO_SMALL: return "output buffer too small";
+        case JPEGENC_E_HIP: return "HIP error or no usable gfx950 device";
+        case JPEGENC_E_UNSUPPORTED: return "unsupported configuration";
+        case JPEGENC_E_NOMEM: return "out of memory";
+        case JPEGENC_E_STATE: return "port protocol misuse";
+        default: return "unknown error";
+    }
+}
+
+const char* jpegenc_last_error(const jpegenc_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+const char* jpegenc_version(void) { return "jpegenc-gfx950 0.1"; }
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+// jpegenc_internal.h -- shared between the HIP kernels and the C-ABI host code of libjpegenc.so.
+#ifndef JPEGENC_INTERNAL_H
+#define JPEGENC_INTERNAL_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "jpegenc.h"
+
+namespace jpegenc {
+
+// A chunk is 64 consecutive MCUs of one image, coded by one wavefront (lane = MCU).
+constexpr int kChunkMcus = 64;
+// Worst case bits per MCU: 3 component blocks x (22 DC + 63 x 26 AC) = 4980 bits = 156 words (rounded up).
+constexpr int kMaxMcuBits = 4980;
+constexpr int kMaxMcuWords = 156;
+// Chunk stream slot in the workspace, in 32-bit words: worst case of 64 MCUs.
+constexpr int kSlotWords = kChunkMcus * kMaxMcuWords;  // 9984 words = 39,936 B
+
+// Packed Huffman table: 256 AC entries indexed by (run << 4 | size), then 16 DC entries by size.
+// entry = ((code << size) << 5) | (code_length + size); 0 = nothing to emit.
+constexpr int kHtabEntries = 272;
+constexpr int kHtabDc = 256;
+constexpr int kNullSym = 0x0F;  // (run 0, size 15): never assigned, entry 0
+
+struct EncodeParams {
+    const uint8_t* rgb;    // first image of this launch
+    int64_t stride;        // bytes per pixel row
+    int64_t image_stride;  // bytes between images
+    uint32_t mcu_w;        // MCUs per block row (w / 8)
+    uint32_t n_mcu;        // MCUs per image
+    uint32_t cpi;          // chunks per image = ceil(n_mcu / 64)
+    uint32_t flags;        // bit 0: rgb wrap quirk, bit 1: cb 6'd64 quirk
+    uint32_t* slots;       // [n_images * cpi][kSlotWords]
+    uint32_t* chunk_bits;  // [n_images * cpi]
+    const uint32_t* htab;  // [kHtabEntries]
+    const int32_t* qmul;   // [3][64] multipliers 4096/Q in Huffman-input order, or nullptr
+};
+
+struct ScanParams {
+    const uint32_t* counts;  // [n_images][cpi]
+    uint64_t* prefix;        // [n_images][cpi] exclusive
+    uint32_t cpi;
+};
+
+struct StuffParams {
+    const uint32_t* slots;
+    const uint32_t* chunk_bits;
+    const uint64_t* bit_off;  // exclusive prefix of chunk_bits per image
+    uint32_t* chunk_ff;       // count pass: number of 0xFF bytes owned by the chunk
+    const uint64_t* ff_off;   // write pass: exclusive prefix of chunk_ff per image
+    uint32_t* words_out;      // first image of this launch
+    uint64_t out_stride;      // words between images
+    uint64_t cap_words;       // capacity per image
+    jpegenc_result* results;  // first image of this launch (device memory)
+    uint32_t cpi;
+};
+
+// Launchers (defined in jpegenc_kernels.hip).  align = 8, 4 or 1: guaranteed alignment of every
+// pixel-row address (rgb, stride, image_stride).
+hipError_t launch_encode(const EncodeParams& p, uint32_t n_images, int align, hipStream_t s);
+hipError_t launch_scan(const ScanParams& p, uint32_t n_images, hipStream_t s);
+hipError_t launch_stuff_count(const StuffParams& p, uint32_t n_images, hipStream_t s);
+hipError_t launch_stuff_write(const StuffParams& p, uint32_t n_images, hipStream_t s);
+
+// Host-side table construction (jpegenc_host.cpp).
+void build_htab(uint32_t out[kHtabEntries]);
+
+}  // namespace jpegenc
+#endif

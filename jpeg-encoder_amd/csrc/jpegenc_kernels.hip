@@ -1,0 +1,634 @@
+// jpegenc_kernels.hip -- gfx950 kernels of the jpeg_top data path.
+//
+// Pipeline per launch group (a sub-batch of images):
+//   k_encode_chunks  RGB -> YCbCr -> 8x8 DCT -> quantise -> Huffman bits.  One wavefront per chunk of
+//                    64 consecutive MCUs, one lane per MCU; everything between the pixel load and the
+//                    lane's bit string stays in registers, the bit strings are concatenated in LDS and
+//                    written once, as the chunk's bit stream, to its workspace slot.
+//   k_scan           exclusive prefix of the per-chunk bit counts (and later of the 0xFF counts) per image.
+//   k_stuff<false>   counts the complete 0xFF bytes each chunk owns once its global bit phase is known.
+//   k_stuff<true>    shifts every chunk stream to its global position, inserts 0x00 after 0xFF, writes
+//                    the 32-bit words and the end-of-file result.
+//
+// Reference arithmetic reproduced here (paths relative to the reference tree):
+//   colour      rtl/1_rbg2ycrcb/rgb2ycrcb.sv:29-39, 77-91, 105-135
+//   DCT         rtl/2_dct/cb_dct.sv:141-157, 198-231, 265-281, 308-375, 392-475, 544-610, 613-808, 826-865
+//               rtl/2_dct/y_dct.sv:41-45, 122, 266, 549-551
+//   quantiser   rtl/3_quantization/y_quantizer.sv:37-46, 58, 74, 106
+//   transpose   rtl/d_q_h/yd_q_h.sv:120-135
+//   entropy     rtl/4_huffman/cr_huff.sv:176-231 (end-of-block), 518-519, 558, 591-596, 629-656, 675-716,
+//               1053-1304 (zig-zag), 1317-1486 (sizes), 1553-2082 (tables); y_huff.sv:184-193; cb_huff.sv:230-243
+//   interleave  rtl/5_fifo/fifo_out.sv:195-197, 222-243, 257-266
+//   stuffing    rtl/5_fifo/ff_checker.sv:96-179, 265-360
+#include "jpegenc_internal.h"
+#include "jpegenc_tables.h"
+
+namespace jpegenc {
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, int lane, uint32_t* total) {
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    *total = __shfl(x, 63);
+    return x - v;
+}
+
+__device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int l) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+}
+
+// zig-zag position (row*8+col, row = vertical frequency) of the k-th coefficient
+__device__ constexpr uint8_t kZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,
+                                        12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6,  7,  14, 21, 28,
+                                        35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51,
+                                        58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// ------------------------------------------------------------------------------------------------
+// 8-point integer DCT-II, y_k = sum_c x_c * T[k][c] with T = round(2^14 * DCT-II).  The rows of T are
+// exactly symmetric (k even) or antisymmetric (k odd), so folding the inputs first changes no integer:
+// every product and sum below is the same integer the RTL's multiply-accumulate produces
+// (cb_dct.sv:433-439, 467-473 for pass 1, :198-231, :265-281 for pass 2).  `bias0` is added to y_0 and
+// `bias` to y_1..7 so that the rounding "bits above n plus the bit below" becomes one arithmetic shift.
+// All operands fit 24 bits (|x| <= 5792, |T| <= 8035), so the 24-bit multiplier is exact.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dct8(int& x0, int& x1, int& x2, int& x3, int& x4, int& x5, int& x6, int& x7,
+                                     int bias0, int bias, int sh) {
+    const int s0 = x0 + x7, s1 = x1 + x6, s2 = x2 + x5, s3 = x3 + x4;
+    const int d0 = x0 - x7, d1 = x1 - x6, d2 = x2 - x5, d3 = x3 - x4;
+    const int e0 = s0 + s3, e1 = s1 + s2, f0 = s0 - s3, f1 = s1 - s2;
+    const int y0 = __mul24(5793, e0 + e1) + bias0;
+    const int y4 = __mul24(5793, e0 - e1) + bias;
+    const int y2 = __mul24(7568, f0) + __mul24(3135, f1) + bias;
+    const int y6 = __mul24(3135, f0) - __mul24(7568, f1) + bias;
+    const int y1 = __mul24(8035, d0) + __mul24(6811, d1) + __mul24(4551, d2) + __mul24(1598, d3) + bias;
+    const int y3 = __mul24(6811, d0) - __mul24(1598, d1) - __mul24(8035, d2) - __mul24(4551, d3) + bias;
+    const int y5 = __mul24(4551, d0) - __mul24(8035, d1) + __mul24(1598, d2) + __mul24(6811, d3) + bias;
+    const int y7 = __mul24(1598, d0) - __mul24(4551, d1) + __mul24(6811, d2) - __mul24(8035, d3) + bias;
+    x0 = y0 >> sh; x1 = y1 >> sh; x2 = y2 >> sh; x3 = y3 >> sh;
+    x4 = y4 >> sh; x5 = y5 >> sh; x6 = y6 >> sh; x7 = y7 >> sh;
+}
+
+__device__ __forceinline__ int sext11(int v) { return (v << 21) >> 21; }
+
+// 2-D transform of one component block held in registers.  In: x[r*8+c] samples 0..255.
+// Out: x[a*8+b] = coefficient (vertical frequency a, horizontal frequency b), i.e. the Huffman coder's
+// input order after the wrapper transpose (yd_q_h.sv:120-135).
+// Luma keeps 13-bit intermediates (round at bit 12, final at bit 16: y_dct.sv:71, 122, 549-551); chroma
+// keeps 11-bit intermediates (round at bit 14 twice: cb_dct.sv:311, 826).  The intermediate wraps of
+// the RTL (25-bit pass-1 snapshots, 13/11-bit B) cannot trigger for 8-bit inputs: |A| < 2^24 and
+// |B| <= 1448 resp. 363; the 25-/32-bit Z registers are taken modulo 2^32 here and only bits below
+// bit 27 are used.
+__device__ __forceinline__ void dct8x8(int (&x)[64], bool luma) {
+    const int sh1 = luma ? 12 : 14;
+    const int sh2 = luma ? 16 : 14;
+    const int b1 = 1 << (sh1 - 1);
+    const int b2 = 1 << (sh2 - 1);
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        dct8(x[r * 8 + 0], x[r * 8 + 1], x[r * 8 + 2], x[r * 8 + 3], x[r * 8 + 4], x[r * 8 + 5], x[r * 8 + 6],
+             x[r * 8 + 7], b1 - JPEGENC_DCT_LEVEL_SHIFT, b1, sh1);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        dct8(x[0 * 8 + k], x[1 * 8 + k], x[2 * 8 + k], x[3 * 8 + k], x[4 * 8 + k], x[5 * 8 + k], x[6 * 8 + k],
+             x[7 * 8 + k], b2, b2, sh2);
+#pragma unroll
+    for (int i = 0; i < 64; ++i) x[i] = sext11(x[i]);  // 11-bit output ports (cb_dct.sv:20-35)
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-lane bit writer: appends (bits,len) MSB-first; full 32-bit words go to the lane's private LDS
+// region.  `cur` keeps the pending bits right-aligned; bits above `n` are stale and shift out.
+// ------------------------------------------------------------------------------------------------
+struct BitWriter {
+    uint32_t cur;   // pending bits (low n bits valid)
+    uint32_t n;     // 0..31
+    uint32_t wp;    // next LDS word index
+    uint32_t wlim;  // first LDS word index this lane may not write
+};
+
+__device__ __forceinline__ void bw_emit(BitWriter& s, uint32_t bits, uint32_t len, uint32_t* priv) {
+    const uint32_t t = s.n + len;  // len <= 26, so t < 64 and a flush implies n >= 6
+    if (t >= 32) {
+        const uint32_t word = (s.cur << (32u - s.n)) | (bits >> (t - 32u));
+        if (s.wp < s.wlim) priv[s.wp] = word;
+        s.wp += 1;
+    }
+    s.cur = (s.cur << len) | bits;
+    s.n = t & 31u;
+}
+
+// Huffman-codes one component block (coefficients in Huffman input order) into the lane's writer.
+// AC algorithm, lane-serial over the zig-zag order (cr_huff.sv:675-685 run counter, :656 forced run 0
+// at the last slot, :558 ZRL only when end_of_block is low, :518 the last slot always emits):
+//   non-zero v : symbol (run<<4)|size10(v), then the low size bits of v (v>=0) or v-1 (v<0)
+//   zero v     : ZRL iff the 4-bit run counter already holds 15 and end_of_block(k) is low
+//   k == 63    : zero -> EOB, non-zero -> ordinary symbol and no EOB
+// size10(v) = bit_length(|v| & 0x3FF): for v >= 0 the highest set bit of v[9:0], for v < 0 the highest
+// clear bit of (v-1)[9:0] (cr_huff.sv:1411-1486); ~(v-1) == -v makes the two cases one expression.
+__device__ __forceinline__ void encode_block(const int (&blk)[64], int dc_pred, bool cb_eob_quirk,
+                                             const uint32_t* htab, uint32_t* priv, BitWriter& bw) {
+    // DC difference, 12 bit (cr_huff.sv:1317): |d| <= 2047 for 11-bit inputs, no wrap possible.
+    {
+        const int d = blk[0] - dc_pred;
+        const uint32_t a = (uint32_t)__builtin_abs(d) & 0x7FFu;
+        const uint32_t size = 32u - (uint32_t)__clz((int)a);
+        const uint32_t amp = (uint32_t)(d + (d >> 31)) & ((1u << size) - 1u);
+        const uint32_t ent = htab[kHtabDc + size];
+        bw_emit(bw, (ent >> 5) | amp, ent & 31u, priv);
+    }
+    // group-of-eight all-zero tests over zig-zag indices 16..63 (cr_huff.sv:190-204)
+    int o2 = 0, o3 = 0, o4 = 0, o5 = 0, o6 = 0, o7 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        o2 |= blk[kZZ[16 + i]];
+        o3 |= blk[kZZ[24 + i]];
+        o4 |= blk[kZZ[32 + i]];
+        o5 |= blk[kZZ[40 + i]];
+        o6 |= blk[kZZ[48 + i]];
+        o7 |= blk[kZZ[56 + i]];
+    }
+    const int t67 = o6 | o7;
+    const int t47 = o4 | o5 | t67;
+    const bool eob_a = (o2 | o3 | t47) == 0;  // block_counter < 32
+    const bool eob_b = t47 == 0;              // block_counter < 48
+    // block_counter <= 64: groups 7,8 -- except in cb_huff, where `6'd64` is 0 and the branch that
+    // sets end_of_block to 1 always wins (cb_huff.sv:238-243)
+    const bool eob_c = cb_eob_quirk || (t67 == 0);
+
+    uint32_t r4 = 0;  // run << 4
+#pragma unroll
+    for (int k = 1; k <= 62; ++k) {
+        const int v = blk[kZZ[k]];
+        const uint32_t a = (uint32_t)__builtin_abs(v) & 0x3FFu;
+        const uint32_t size = 32u - (uint32_t)__clz((int)a);
+        const uint32_t amp = (uint32_t)(v + (v >> 31)) & ((1u << size) - 1u);
+        const bool nz = v != 0;
+        bool emit = nz;
+        if (k >= 16) {  // a run of 15 zeros cannot complete before k = 16
+            const bool eob = (k + 2 < 32) ? eob_a : (k + 2 < 48) ? eob_b : eob_c;
+            emit = nz || (r4 == 0xF0u && !eob);
+        }
+        const uint32_t ent = htab[emit ? (r4 | size) : (uint32_t)kNullSym];
+        bw_emit(bw, (ent >> 5) | amp, ent & 31u, priv);
+        r4 = nz ? 0u : ((r4 + 16u) & 0xF0u);
+    }
+    {
+        const int v = blk[63];
+        const uint32_t a = (uint32_t)__builtin_abs(v) & 0x3FFu;
+        const uint32_t size = 32u - (uint32_t)__clz((int)a);
+        const uint32_t amp = (uint32_t)(v + (v >> 31)) & ((1u << size) - 1u);
+        const uint32_t ent = htab[(v != 0) ? (r4 | size) : 0u];
+        bw_emit(bw, (ent >> 5) | amp, ent & 31u, priv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pixel loads: 8 rows x 24 bytes of one MCU into 48 dwords (row r -> raw[6r..6r+5])
+// ------------------------------------------------------------------------------------------------
+template <int ALIGN>
+__device__ __forceinline__ void load_mcu(const uint8_t* src, int64_t stride, uint32_t (&raw)[48]) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const uint8_t* row = src + (int64_t)r * stride;
+        if constexpr (ALIGN == 8) {
+            const uint2* q = reinterpret_cast<const uint2*>(row);
+            const uint2 a = q[0], b = q[1], c = q[2];
+            raw[r * 6 + 0] = a.x; raw[r * 6 + 1] = a.y; raw[r * 6 + 2] = b.x;
+            raw[r * 6 + 3] = b.y; raw[r * 6 + 4] = c.x; raw[r * 6 + 5] = c.y;
+        } else if constexpr (ALIGN == 4) {
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(row);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) raw[r * 6 + i] = q[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                raw[r * 6 + i] = (uint32_t)row[4 * i] | ((uint32_t)row[4 * i + 1] << 8) |
+                                 ((uint32_t)row[4 * i + 2] << 16) | ((uint32_t)row[4 * i + 3] << 24);
+        }
+    }
+}
+
+// byte j (0..23) of row r
+__device__ __forceinline__ uint32_t raw_byte(const uint32_t (&raw)[48], int r, int j) {
+    return (raw[r * 6 + (j >> 2)] >> (8 * (j & 3))) & 0xFFu;
+}
+
+// One colour component of one pixel (rgb2ycrcb.sv:77-91 sums, :105-135 rounding).  k0 carries the
+// +2^21 offset of Cb/Cr and the rounding bit 2^13.  The 22-bit sums are never negative, so the
+// arithmetic shift is the RTL's bit slice; `& 0xFF` is the 8-bit wrap of the rounder (255 + 1 -> 0).
+__device__ __forceinline__ int colour(uint32_t R, uint32_t G, uint32_t B, int k0, int cr, int cg, int cb, bool wrap) {
+    const int s = k0 + __mul24(cr, (int)R) + __mul24(cg, (int)G) + __mul24(cb, (int)B);
+    const int v = s >> 14;
+    return wrap ? (v & 0xFF) : min(v, 255);
+}
+
+struct CompCoef {
+    int k0, cr, cg, cb;
+};
+__device__ __forceinline__ CompCoef comp_coef(int comp) {
+    CompCoef c;
+    c.k0 = (comp == 0) ? 8192 : (JPEGENC_C_OFFSET + 8192);
+    c.cr = (comp == 0) ? JPEGENC_Y_R : (comp == 1) ? -JPEGENC_CB_R : JPEGENC_CR_R;
+    c.cg = (comp == 0) ? JPEGENC_Y_G : (comp == 1) ? -JPEGENC_CB_G : -JPEGENC_CR_G;
+    c.cb = (comp == 0) ? JPEGENC_Y_B : (comp == 1) ? JPEGENC_CB_B : -JPEGENC_CR_B;
+    return c;
+}
+
+// quantiser (y_quantizer.sv:58, 74, 106): 11-bit result of (F * (4096/Q) + 2048) >> 12; the 23-bit
+// product register only drops bits that the 11-bit result does not see.
+__device__ __forceinline__ int quant(int f, int qm) { return sext11((f * qm + 2048) >> 12); }
+
+// DC coefficient of one component of the MCU *before* this chunk, computed by the whole wave (lane =
+// pixel): needed as the DC predictor of lane 0.  Same arithmetic as dct8x8 restricted to k = j = 0.
+__device__ __forceinline__ int halo_dc(int sample, bool luma, int qm0, bool do_quant) {
+    int s = sample;
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);  // row sum, identical in the 8 lanes of a row
+    const int sh1 = luma ? 12 : 14, sh2 = luma ? 16 : 14;
+    int b = (__mul24(5793, s) - JPEGENC_DCT_LEVEL_SHIFT + (1 << (sh1 - 1))) >> sh1;
+    b += __shfl_xor(b, 8);
+    b += __shfl_xor(b, 16);
+    b += __shfl_xor(b, 32);  // sum over the 8 rows
+    int f = sext11((__mul24(5793, b) + (1 << (sh2 - 1))) >> sh2);
+    if (do_quant) f = quant(f, qm0);
+    return f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_encode_chunks
+// ------------------------------------------------------------------------------------------------
+// LDS budget: 64 regions of 65 words.  Tier 1 gives every lane one region (63 usable words = 2016 bits
+// per MCU, enough for photographic content); if any lane overflows, the chunk is redone with 2 groups of
+// 32 lanes (two regions each, 4096 bits), then with 4 groups of 16 lanes (four regions, 258 words -- more
+// than the 156-word worst case of an MCU).  Odd region strides keep lanes on different LDS banks.
+constexpr int kRegionWords = 65;
+constexpr int kPrivWords = 64 * kRegionWords;  // 4160 words = 16,640 B
+
+template <int ALIGN, bool QUANT>
+__global__ __launch_bounds__(64, 2) void k_encode_chunks(EncodeParams p) {
+    __shared__ uint32_t priv[kPrivWords];
+    __shared__ uint32_t htab[kHtabEntries];
+    const int lane = threadIdx.x;
+    const uint32_t gid = blockIdx.x;
+    const uint32_t img = gid / p.cpi;
+    const uint32_t c = gid - img * p.cpi;
+    const bool rgb_wrap = (p.flags & 1u) != 0;
+    const bool cb_quirk = (p.flags & 2u) != 0;
+
+    for (int i = lane; i < kHtabEntries; i += 64) htab[i] = p.htab[i];
+
+    const uint32_t b = c * kChunkMcus + lane;
+    const bool valid = b < p.n_mcu;
+    const uint32_t bb = valid ? b : (p.n_mcu - 1);
+    const uint32_t by = bb / p.mcu_w;
+    const uint32_t bx = bb - by * p.mcu_w;
+    const uint8_t* img_base = p.rgb + (int64_t)img * p.image_stride;
+    const uint8_t* src = img_base + (int64_t)by * 8 * p.stride + (int64_t)bx * 24;
+
+    uint32_t raw[48];
+    load_mcu<ALIGN>(src, p.stride, raw);
+
+    // DC predictors for lane 0: the MCU just before this chunk (0 at the start of an image: rst)
+    int halo[3] = {0, 0, 0};
+    if (c > 0) {
+        const uint32_t hb = c * kChunkMcus - 1;
+        const uint32_t hy = hb / p.mcu_w, hx = hb - hy * p.mcu_w;
+        const uint8_t* hp = img_base + ((int64_t)hy * 8 + (lane >> 3)) * p.stride + (int64_t)hx * 24 + (lane & 7) * 3;
+        const uint32_t R = hp[0], G = hp[1], B = hp[2];
+#pragma unroll
+        for (int comp = 0; comp < 3; ++comp) {
+            const CompCoef cc = comp_coef(comp);
+            const int smp = colour(R, G, B, cc.k0, cc.cr, cc.cg, cc.cb, rgb_wrap);
+            halo[comp] = halo_dc(smp, comp == 0, QUANT ? p.qmul[comp * 64] : 4096, QUANT);
+        }
+    }
+    __syncthreads();  // htab visible
+
+    uint32_t* slot = p.slots + (uint64_t)gid * kSlotWords;
+    uint32_t chunk_total = 0;  // bits written to the slot so far
+    uint32_t carry = 0;        // partial last word of the slot (left-aligned), when chunk_total % 32 != 0
+
+    // Tier loop: n_groups = 1, 2 or 4 groups of 64/n_groups lanes coding at once (see kRegionWords).
+    int n_groups = 1;
+    for (int g = 0; g < n_groups; ++g) {
+        const int lanes_per_group = 64 / n_groups;
+        const uint32_t stride = (uint32_t)kRegionWords * (uint32_t)n_groups;
+        const uint32_t cap = stride - 2u;
+        const bool active = valid && (lane / lanes_per_group) == g;
+        const uint32_t base = (uint32_t)(lane & (lanes_per_group - 1)) * stride;
+        BitWriter bw;
+        bw.cur = 0;
+        bw.n = 0;
+        bw.wp = base;
+        bw.wlim = active ? base + cap : base;
+
+#pragma unroll 1
+        for (int comp = 0; comp < 3; ++comp) {
+            const CompCoef cc = comp_coef(comp);
+            int x[64];
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    x[r * 8 + q] = colour(raw_byte(raw, r, 3 * q), raw_byte(raw, r, 3 * q + 1), raw_byte(raw, r, 3 * q + 2),
+                                          cc.k0, cc.cr, cc.cg, cc.cb, rgb_wrap);
+            dct8x8(x, comp == 0);
+            if constexpr (QUANT) {
+                const int32_t* qm = p.qmul + comp * 64;
+#pragma unroll
+                for (int i = 0; i < 64; ++i) x[i] = quant(x[i], qm[i]);
+            }
+            int pred = __shfl_up(x[0], 1);
+            const int h = (comp == 0) ? halo[0] : (comp == 1) ? halo[1] : halo[2];
+            if (lane == 0) pred = h;
+            encode_block(x, pred, comp == 1 && cb_quirk, htab, priv, bw);
+        }
+        // flush the residual bits, left-aligned and zero-filled
+        if (bw.n != 0 && bw.wp < bw.wlim) priv[bw.wp] = bw.cur << (32u - bw.n);
+        // Every lane counts its bits whether or not it may store them, so the first pass already knows
+        // which tier the chunk needs.
+        const uint32_t Lall = valid ? ((bw.wp - base) * 32u + bw.n) : 0u;
+        if (n_groups == 1 && __any((int)(Lall > cap * 32u))) {
+            n_groups = __any((int)(Lall > (2u * kRegionWords - 2u) * 32u)) ? 4 : 2;
+            g = -1;  // restart the chunk on that tier
+            __syncthreads();
+            continue;
+        }
+        const uint32_t L = active ? Lall : 0u;  // bits of this lane's string in this group
+        __syncthreads();  // strings visible to all lanes
+
+        // ---- concatenate the group's strings in place, in lane order, at LDS word 0 -------------
+        uint32_t gtotal;
+        const uint32_t off = wave_excl_scan_u32(L, lane, &gtotal);
+        const int first = g * lanes_per_group;
+        for (int m = 0; m < lanes_per_group; ++m) {
+            const int M = first + m;
+            const uint32_t LM = readlane_u32(L, M);
+            if (LM == 0) continue;  // uniform
+            const uint32_t oM = readlane_u32(off, M);
+            const uint32_t bM = (uint32_t)m * stride;
+            const uint32_t s = oM & 31u, d0 = oM >> 5;
+            const uint32_t nw = (LM + 31u) >> 5;          // source words
+            const uint32_t nd = (s + LM + 31u) >> 5;      // destination words touched
+            for (uint32_t t0 = 0; t0 < nd; t0 += 64) {
+                const uint32_t t = t0 + lane;
+                const uint32_t lo = (t < nw) ? priv[bM + t] : 0u;
+                const uint32_t hi = (t >= 1 && t - 1 < nw) ? priv[bM + t - 1] : 0u;
+                uint32_t w = s ? ((hi << (32u - s)) | (lo >> s)) : lo;
+                const uint32_t old = (t == 0 && s) ? priv[d0] : 0u;  // bits of the previous strings
+                __syncthreads();  // all reads of this round before its writes
+                if (t < nd) priv[d0 + t] = w | old;
+                __syncthreads();
+            }
+        }
+
+        // ---- append the group's stream to the slot at bit offset chunk_total ---------------------
+        if (gtotal != 0) {
+            const uint32_t s = chunk_total & 31u, d0 = chunk_total >> 5;
+            const uint32_t nw = (gtotal + 31u) >> 5;
+            const uint32_t nd = (s + gtotal + 31u) >> 5;
+            for (uint32_t t = lane; t < nd; t += 64) {
+                const uint32_t lo = (t < nw) ? priv[t] : 0u;
+                const uint32_t hi = (t >= 1 && t - 1 < nw) ? priv[t - 1] : 0u;
+                uint32_t w = s ? ((hi << (32u - s)) | (lo >> s)) : lo;
+                if (t == 0) w |= carry;
+                slot[d0 + t] = w;
+            }
+            const uint32_t nt = chunk_total + gtotal;
+            if (nt & 31u) {  // keep the partial last word for the next group (uniform)
+                const uint32_t t = nd - 1;
+                const uint32_t lo = (t < nw) ? priv[t] : 0u;
+                const uint32_t hi = (t >= 1 && t - 1 < nw) ? priv[t - 1] : 0u;
+                uint32_t w = s ? ((hi << (32u - s)) | (lo >> s)) : lo;
+                if (t == 0) w |= carry;
+                carry = w;
+            } else {
+                carry = 0;
+            }
+            chunk_total = nt;
+        }
+        __syncthreads();  // LDS free for the next group
+    }
+    if (lane == 0) p.chunk_bits[gid] = chunk_total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_scan: exclusive prefix per image, one 256-thread workgroup per image.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scan(ScanParams p) {
+    __shared__ uint64_t part[256];
+    const uint32_t img = blockIdx.x;
+    const uint32_t* in = p.counts + (uint64_t)img * p.cpi;
+    uint64_t* out = p.prefix + (uint64_t)img * p.cpi;
+    const uint32_t per = (p.cpi + 255u) / 256u;
+    const uint32_t lo = min(threadIdx.x * per, p.cpi), hi = min(lo + per, p.cpi);
+    uint64_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += in[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        uint64_t v = (threadIdx.x >= (unsigned)d) ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint64_t run = part[threadIdx.x] - sum;
+    for (uint32_t i = lo; i < hi; ++i) {
+        out[i] = run;
+        run += in[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_stuff: one wavefront per chunk.
+// The image's unstuffed stream is the concatenation of its chunk streams; chunk c covers global bits
+// [o, o+n).  A byte of that stream is owned by the chunk holding its last bit, so chunk c owns bytes
+// [o>>3, (o+n)>>3): its first byte may begin in the previous chunk (every chunk has >= 1152 bits, so
+// at most one byte, and at most one predecessor, is involved).  Owned bytes equal to 0xFF get 0x00
+// after them (ff_checker.sv:96-179).  Output byte i of the stuffed stream lives in word i/4 at bits
+// 31-8*(i%4), i.e. at byte address i^3 of a little-endian word array.
+// ------------------------------------------------------------------------------------------------
+template <bool WRITE>
+__global__ __launch_bounds__(64) void k_stuff(StuffParams p) {
+    __shared__ uint32_t ring_w[256];  // 1 KiB window of the stuffed byte stream, byte i at (i & 1023) ^ 3
+    uint8_t* ring = reinterpret_cast<uint8_t*>(ring_w);
+    const int lane = threadIdx.x;
+    const uint32_t gid = blockIdx.x;
+    const uint32_t img = gid / p.cpi;
+    const uint32_t c = gid - img * p.cpi;
+    const uint32_t n = p.chunk_bits[gid];
+    const uint64_t o = p.bit_off[gid];
+    const uint32_t* S = p.slots + (uint64_t)gid * kSlotWords;
+
+    // last 32 bits of the predecessor's stream (it has >= 1152 bits)
+    uint32_t pw = 0;
+    if (c > 0) {
+        const uint32_t np = p.chunk_bits[gid - 1];
+        const uint32_t* Sp = S - kSlotWords;
+        const uint32_t l = np - 32u, wi = l >> 5, s = l & 31u;
+        const uint32_t w0 = Sp[wi];
+        pw = s ? ((w0 << s) | (Sp[wi + 1] >> (32u - s))) : w0;
+    }
+    const uint64_t q_first = o >> 3;
+    const uint64_t q_end = (o + n) >> 3;
+    const uint32_t nbytes = (uint32_t)(q_end - q_first);
+    const int lstart = -(int)(o & 7u);  // local bit position of the first owned byte
+
+    auto fetch32 = [&](int l) -> uint32_t {  // 32 stream bits starting at local bit l (l >= -7)
+        const int wi = l >> 5;
+        const uint32_t s = (uint32_t)l & 31u;
+        const uint32_t w0 = (wi < 0) ? pw : S[wi];
+        const uint32_t w1 = S[wi + 1];
+        return s ? ((w0 << s) | (w1 >> (32u - s))) : w0;
+    };
+
+    uint32_t* out_words = nullptr;
+    uint8_t* out_bytes = nullptr;
+    uint64_t pos = 0, pos0 = 0, wdone = 0;
+    if constexpr (WRITE) {
+        out_words = p.words_out + (uint64_t)img * p.out_stride;
+        out_bytes = reinterpret_cast<uint8_t*>(out_words);
+        pos0 = pos = q_first + p.ff_off[gid];  // stuffed byte offset of the first owned byte
+        wdone = (pos + 3) >> 2;                // first word this chunk writes whole
+    }
+    const uint64_t cap_bytes = p.cap_words * 4;
+    uint32_t ff_total = 0;
+    bool head_done = false;
+
+    for (uint32_t base = 0; base < nbytes; base += 256) {
+        const uint32_t j = base + (uint32_t)lane * 4u;
+        const int nvalid = (j < nbytes) ? (int)min(4u, nbytes - j) : 0;
+        uint32_t v = 0;
+        if (nvalid > 0) v = fetch32(lstart + 8 * (int)j);
+        uint32_t ffm = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < nvalid && ((v >> (24 - 8 * i)) & 0xFFu) == 0xFFu) ffm |= 1u << i;
+        const uint32_t cnt = __popc(ffm);
+        if constexpr (!WRITE) {
+            ff_total += cnt;
+        } else {
+            uint32_t it_ff;
+            const uint32_t pre = wave_excl_scan_u32(cnt, lane, &it_ff);
+            uint64_t a = pos + j - base + pre;  // stuffed offset of this lane's first byte
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i < nvalid) {
+                    ring[((uint32_t)a & 1023u) ^ 3u] = (uint8_t)(v >> (24 - 8 * i));
+                    ++a;
+                    if (ffm & (1u << i)) {
+                        ring[((uint32_t)a & 1023u) ^ 3u] = 0;
+                        ++a;
+                    }
+                }
+            }
+            const uint32_t it_bytes = min(256u, nbytes - base) + it_ff;
+            pos += it_bytes;
+            __syncthreads();
+            if (!head_done) {  // bytes before the first whole word: stored one by one
+                const uint64_t hend = min(wdone * 4, pos);
+                const uint64_t ha = pos0 + lane;
+                if (ha < hend && ha < cap_bytes) out_bytes[ha ^ 3] = ring[((uint32_t)ha & 1023u) ^ 3u];
+                head_done = true;
+            }
+            const uint64_t wend = pos >> 2;  // words complete so far
+            for (uint64_t w = wdone + lane; w < wend; w += 64)
+                if (w < p.cap_words) out_words[w] = ring_w[(uint32_t)w & 255u];
+            if (wend > wdone) wdone = wend;
+            __syncthreads();
+        }
+    }
+
+    if constexpr (!WRITE) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) ff_total += __shfl_xor(ff_total, d);
+        if (lane == 0) p.chunk_ff[gid] = ff_total;
+    } else {
+        const bool last = (c == p.cpi - 1);
+        if (!last) {
+            // bytes after the last whole word belong to a word shared with the next chunk
+            const uint64_t ta = wdone * 4 + lane;
+            if (ta >= pos0 && ta < pos && ta < cap_bytes) out_bytes[ta ^ 3] = ring[((uint32_t)ta & 1023u) ^ 3u];
+        } else {
+            // end of file: the incomplete last byte is never stuffed; the residual bits are presented
+            // left-aligned in one more word with their count (ff_checker.sv:289-360, functional)
+            const uint64_t total_bits = o + n;
+            const uint32_t rem = (uint32_t)(total_bits & 7u);
+            const uint64_t stuffed_bytes = pos;
+            uint64_t endpos = pos;
+            if (lane == 0) {
+                if (rem) {
+                    const uint32_t vb = fetch32((int)(n - rem)) >> 24;
+                    ring[((uint32_t)endpos & 1023u) ^ 3u] = (uint8_t)(vb & (0xFFu << (8u - rem)));
+                    ++endpos;
+                }
+                while (endpos & 3u) {
+                    ring[((uint32_t)endpos & 1023u) ^ 3u] = 0;
+                    ++endpos;
+                }
+            }
+            endpos = __shfl(endpos, 0);
+            __syncthreads();
+            const uint64_t wend = endpos >> 2;
+            for (uint64_t w = wdone + lane; w < wend; w += 64)
+                if (w < p.cap_words) out_words[w] = ring_w[(uint32_t)w & 255u];
+            if (lane == 0) {
+                const uint64_t sbits = stuffed_bytes * 8 + rem;
+                jpegenc_result r;
+                r.n_full_words = sbits >> 5;
+                r.total_bits_unstuffed = total_bits;
+                r.total_bytes_stuffed = stuffed_bytes;
+                r.tail_bits = (uint8_t)(sbits & 31u);
+                r.eof_partial_ready = r.tail_bits ? 1 : 0;
+                r.tail_word = r.tail_bits ? ring_w[(uint32_t)(r.n_full_words) & 255u] : 0u;
+                const uint64_t need = r.n_full_words + (r.tail_bits ? 1 : 0);
+                r.status = (need > p.cap_words) ? (int16_t)JPEGENC_E_TOO_SMALL : (int16_t)JPEGENC_OK;
+                p.results[img] = r;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+template <int ALIGN>
+static hipError_t launch_encode_a(const EncodeParams& p, uint32_t grid, hipStream_t s) {
+    if (p.qmul)
+        hipLaunchKernelGGL((k_encode_chunks<ALIGN, true>), dim3(grid), dim3(64), 0, s, p);
+    else
+        hipLaunchKernelGGL((k_encode_chunks<ALIGN, false>), dim3(grid), dim3(64), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_encode(const EncodeParams& p, uint32_t n_images, int align, hipStream_t s) {
+    const uint64_t grid = (uint64_t)n_images * p.cpi;
+    if (grid == 0 || grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    if (align >= 8) return launch_encode_a<8>(p, (uint32_t)grid, s);
+    if (align >= 4) return launch_encode_a<4>(p, (uint32_t)grid, s);
+    return launch_encode_a<1>(p, (uint32_t)grid, s);
+}
+
+hipError_t launch_scan(const ScanParams& p, uint32_t n_images, hipStream_t s) {
+    hipLaunchKernelGGL(k_scan, dim3(n_images), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_stuff_count(const StuffParams& p, uint32_t n_images, hipStream_t s) {
+    hipLaunchKernelGGL((k_stuff<false>), dim3(n_images * p.cpi), dim3(64), 0, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_stuff_write(const StuffParams& p, uint32_t n_images, hipStream_t s) {
+    hipLaunchKernelGGL((k_stuff<true>), dim3(n_images * p.cpi), dim3(64), 0, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace jpegenc

@@ -1,0 +1,236 @@
+"""ctypes binding of libjpegenc.so -- the jpeg_top data path on MI355X.
+
+The reference's only interface is the port list of rtl/0_jpeg_top/jpeg_top.sv:18-28; the method names
+below follow those ports (reset = rst, push_pixel = enable + data_in, end_of_file =
+end_of_file_signal, words = JPEG_bitstream under data_ready, tail_bits =
+end_of_file_bitstream_count, eof_partial_ready = eof_data_partial_ready).  Everything computes in
+the HIP library; if it cannot be loaded or no gfx950 device is usable, calls raise -- there is no
+CPU path in this package.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjpegenc.so")
+
+OK, E_BAD_ARG, E_TOO_SMALL, E_HIP, E_UNSUPPORTED, E_NOMEM, E_STATE = 0, -1, -2, -3, -4, -5, -6
+HOST_PTRS, DEVICE_PTRS = 0, 1
+N_KERNELS = 4
+
+# every symbol include/jpegenc.h declares
+ABI_SYMBOLS = [
+    "jpegenc_default_config", "jpegenc_create", "jpegenc_destroy", "jpegenc_set_stream", "jpegenc_synchronize",
+    "jpegenc_max_words", "jpegenc_encode_rgb8", "jpegenc_encode_batch", "jpegenc_encode_stripes", "jpegenc_reset",
+    "jpegenc_push_pixel", "jpegenc_push_pixels", "jpegenc_end_of_file", "jpegenc_read_words",
+    "jpegenc_words_to_bytes", "jpegenc_set_profiling", "jpegenc_kernel_times", "jpegenc_kernel_name",
+    "jpegenc_set_workspace_limit", "jpegenc_strerror", "jpegenc_last_error", "jpegenc_version",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [("qtab", (C.c_uint16 * 64) * 3),
+                ("quirk_rgb_wrap", C.c_uint8), ("quirk_cb_6d64", C.c_uint8),
+                ("quirk_ydct_zext", C.c_uint8), ("reserved", C.c_uint8),
+                ("device", C.c_int32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("n_full_words", C.c_uint64), ("total_bits_unstuffed", C.c_uint64),
+                ("total_bytes_stuffed", C.c_uint64), ("tail_word", C.c_uint32),
+                ("tail_bits", C.c_uint8), ("eof_partial_ready", C.c_uint8), ("status", C.c_int16)]
+
+
+RESULT_DTYPE = np.dtype([("n_full_words", "<u8"), ("total_bits_unstuffed", "<u8"), ("total_bytes_stuffed", "<u8"),
+                         ("tail_word", "<u4"), ("tail_bits", "u1"), ("eof_partial_ready", "u1"), ("status", "<i2")])
+assert RESULT_DTYPE.itemsize == C.sizeof(Result) == 32
+
+
+class JpegEncError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("jpegenc error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Loads libjpegenc.so (raises OSError if it has not been built)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    L = C.CDLL(path or LIB_PATH)
+    vp, sz, i32, u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint32
+    L.jpegenc_default_config.argtypes = [C.POINTER(Config)]
+    L.jpegenc_create.argtypes = [C.POINTER(vp), C.POINTER(Config)]
+    L.jpegenc_destroy.argtypes = [vp]
+    L.jpegenc_set_stream.argtypes = [vp, vp]
+    L.jpegenc_synchronize.argtypes = [vp]
+    L.jpegenc_max_words.argtypes = [i32, i32]
+    L.jpegenc_max_words.restype = sz
+    L.jpegenc_encode_rgb8.argtypes = [vp, vp, i32, i32, C.c_ssize_t, u32, vp, sz, vp]
+    L.jpegenc_encode_batch.argtypes = [vp, vp, i32, i32, i32, C.c_ssize_t, C.c_ssize_t, u32, vp, sz, vp]
+    L.jpegenc_encode_stripes.argtypes = [vp, vp, i32, i32, C.c_ssize_t, i32, u32, vp, sz, vp]
+    L.jpegenc_reset.argtypes = [vp]
+    L.jpegenc_push_pixel.argtypes = [vp, u32]
+    L.jpegenc_push_pixels.argtypes = [vp, vp, sz]
+    L.jpegenc_end_of_file.argtypes = [vp, C.POINTER(Result)]
+    L.jpegenc_read_words.argtypes = [vp, vp, sz, C.POINTER(sz)]
+    L.jpegenc_words_to_bytes.argtypes = [vp, C.POINTER(Result), vp, sz, C.POINTER(sz)]
+    L.jpegenc_set_profiling.argtypes = [vp, i32]
+    L.jpegenc_kernel_times.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_double), i32]
+    L.jpegenc_kernel_name.argtypes = [i32]
+    L.jpegenc_kernel_name.restype = C.c_char_p
+    L.jpegenc_set_workspace_limit.argtypes = [vp, sz]
+    L.jpegenc_strerror.argtypes = [i32]
+    L.jpegenc_strerror.restype = C.c_char_p
+    L.jpegenc_last_error.argtypes = [vp]
+    L.jpegenc_last_error.restype = C.c_char_p
+    L.jpegenc_version.restype = C.c_char_p
+    if path is None:
+        _lib = L
+    return L
+
+
+def max_words(w, h):
+    return int(load_library().jpegenc_max_words(w, h))
+
+
+class JpegTop:
+    """One instance of the jpeg_top path bound to a GPU (one context = one device + one stream)."""
+
+    def __init__(self, qtabs=None, rgb_wrap=True, cb_6d64=True, device=0, stream=None):
+        self.lib = load_library()
+        cfg = Config()
+        self.lib.jpegenc_default_config(C.byref(cfg))
+        if qtabs is not None:
+            for c in range(3):
+                for i in range(64):
+                    cfg.qtab[c][i] = int(qtabs[c][i])
+        cfg.quirk_rgb_wrap = int(rgb_wrap)
+        cfg.quirk_cb_6d64 = int(cb_6d64)
+        cfg.device = int(device)
+        self.device = int(device)
+        self._ctx = C.c_void_p()
+        rc = self.lib.jpegenc_create(C.byref(self._ctx), C.byref(cfg))
+        if rc != OK:
+            self._ctx = None
+            raise JpegEncError(rc, self.lib.jpegenc_strerror(rc).decode())
+        if stream is not None:
+            self.set_stream(stream)
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _check(self, rc, allow=()):
+        if rc != OK and rc not in allow:
+            detail = self.lib.jpegenc_last_error(self._ctx).decode()
+            raise JpegEncError(rc, self.lib.jpegenc_strerror(rc).decode() + (" (" + detail + ")" if detail else ""))
+        return rc
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self.lib.jpegenc_destroy(self._ctx)
+            self._ctx = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_stream(self, hip_stream):
+        """hip_stream: integer handle (e.g. torch.cuda.current_stream().cuda_stream) or None."""
+        self._check(self.lib.jpegenc_set_stream(self._ctx, C.c_void_p(hip_stream or None)))
+
+    def synchronize(self):
+        self._check(self.lib.jpegenc_synchronize(self._ctx))
+
+    def set_workspace_limit(self, nbytes):
+        self._check(self.lib.jpegenc_set_workspace_limit(self._ctx, int(nbytes)))
+
+    def set_profiling(self, on):
+        self._check(self.lib.jpegenc_set_profiling(self._ctx, int(bool(on))))
+
+    def kernel_times(self, reset=True):
+        n = (C.c_uint64 * N_KERNELS)()
+        ms = (C.c_double * N_KERNELS)()
+        self._check(self.lib.jpegenc_kernel_times(self._ctx, n, ms, int(reset)))
+        return {self.lib.jpegenc_kernel_name(i).decode(): (int(n[i]), float(ms[i])) for i in range(N_KERNELS)}
+
+    # -- raster API (host memory) -----------------------------------------------------------
+    def encode(self, rgb, cap_words=None):
+        """rgb: (h, w, 3) uint8 numpy array.  Returns (words incl. tail word, result record)."""
+        words, res = self.encode_batch(rgb[None], cap_words)
+        return words[0], res[0]
+
+    def encode_batch(self, rgb, cap_words=None, allow_too_small=False):
+        """rgb: (n, h, w, 3) uint8 numpy array.  Returns (list of word arrays, results array)."""
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        n, h, w, _ = rgb.shape
+        cap = int(cap_words or max_words(w, h))
+        words = np.zeros((n, cap), dtype=np.uint32)
+        res = np.zeros(n, dtype=RESULT_DTYPE)
+        rc = self.lib.jpegenc_encode_batch(self._ctx, rgb.ctypes.data, n, w, h, w * 3, h * w * 3, HOST_PTRS,
+                                           words.ctypes.data, cap, res.ctypes.data)
+        self._check(rc, allow=(E_TOO_SMALL,) if allow_too_small else ())
+        out = []
+        for i in range(n):
+            k = min(cap, int(res[i]["n_full_words"]) + (1 if res[i]["tail_bits"] else 0))
+            out.append(words[i, :k].copy())
+        return out, res
+
+    def encode_stripes(self, rgb, n_stripes, cap_words=None):
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        h, w, _ = rgb.shape
+        cap = int(cap_words or max_words(w, h // n_stripes))
+        words = np.zeros((n_stripes, cap), dtype=np.uint32)
+        res = np.zeros(n_stripes, dtype=RESULT_DTYPE)
+        self._check(self.lib.jpegenc_encode_stripes(self._ctx, rgb.ctypes.data, w, h, w * 3, n_stripes, HOST_PTRS,
+                                                    words.ctypes.data, cap, res.ctypes.data))
+        return [words[i, :int(res[i]["n_full_words"]) + (1 if res[i]["tail_bits"] else 0)].copy()
+                for i in range(n_stripes)], res
+
+    # -- raster API (device memory, asynchronous on the context's stream) -------------------
+    def encode_batch_device(self, rgb_ptr, n, w, h, stride, image_stride, words_ptr, cap_words, results_ptr):
+        """All three pointers are device addresses (ints); only enqueues work."""
+        self._check(self.lib.jpegenc_encode_batch(self._ctx, C.c_void_p(rgb_ptr), n, w, h, stride, image_stride,
+                                                  DEVICE_PTRS, C.c_void_p(words_ptr), cap_words,
+                                                  C.c_void_p(results_ptr)))
+
+    # -- port-level protocol -----------------------------------------------------------------
+    def reset(self):
+        self._check(self.lib.jpegenc_reset(self._ctx))
+
+    def push_pixel(self, data_in24):
+        self._check(self.lib.jpegenc_push_pixel(self._ctx, int(data_in24) & 0xFFFFFF))
+
+    def push_pixels(self, data_in24):
+        a = np.ascontiguousarray(data_in24, dtype=np.uint32)
+        self._check(self.lib.jpegenc_push_pixels(self._ctx, a.ctypes.data, a.size))
+
+    def end_of_file(self):
+        """Returns (words, Result) -- the data_ready words followed by the partial word, if any."""
+        res = Result()
+        self._check(self.lib.jpegenc_end_of_file(self._ctx, C.byref(res)))
+        n = C.c_size_t()
+        self.lib.jpegenc_read_words(self._ctx, None, 0, C.byref(n))
+        words = np.zeros(max(1, n.value), dtype=np.uint32)
+        self._check(self.lib.jpegenc_read_words(self._ctx, words.ctypes.data, words.size, C.byref(n)))
+        return words[:n.value].copy(), res
+
+
+def words_to_bytes(words, n_full_words, tail_bits):
+    """Big-endian byte view of the word stream, truncated to the valid bits (rounded up to bytes)."""
+    nbits = int(n_full_words) * 32 + int(tail_bits)
+    return np.asarray(words, dtype=np.uint32).astype(">u4").tobytes()[:(nbits + 7) // 8]
+
+
+def raster_to_port_order(rgb):
+    """(h, w, 3) uint8 -> data_in[23:0] values in the order jpeg_top expects them: block by block,
+    left to right, top to bottom, 64 pixels per block row-major, {B,G,R} with R in bits 7:0."""
+    h, w, _ = rgb.shape
+    blocks = rgb.reshape(h // 8, 8, w // 8, 8, 3).transpose(0, 2, 1, 3, 4).reshape(-1, 3).astype(np.uint32)
+    return blocks[:, 0] | (blocks[:, 1] << 8) | (blocks[:, 2] << 16)

@@ -1,0 +1,249 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit for bit.
+
+The bar is exact equality of every 32-bit word, of the tail word/count and of the sizes.  The oracle
+itself is pinned only by the RTL text, an independent numpy restatement and hand-derived known
+answers (the reference ships no vectors): see oracle/jpegenc_ref.h.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import load_pkg, natural_like
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def enc():
+    pkg = load_pkg()
+    e = pkg.JpegTop()
+    yield e
+    e.close()
+
+
+def assert_same(words, res, rgb, cfg=None):
+    want, r = O.encode(rgb, cfg)
+    assert int(res["total_bits_unstuffed"]) == r.total_bits_unstuffed
+    assert int(res["total_bytes_stuffed"]) == r.total_bytes_stuffed
+    assert int(res["n_full_words"]) == r.n_full_words
+    assert int(res["tail_bits"]) == r.tail_bits
+    assert int(res["eof_partial_ready"]) == r.eof_partial_ready
+    assert int(res["tail_word"]) == r.tail_word
+    assert int(res["status"]) == 0
+    assert len(words) == len(want)
+    if not np.array_equal(words, want):
+        bad = int(np.nonzero(words != want)[0][0])
+        raise AssertionError("first differing word %d of %d: got %08x want %08x" % (bad, len(want), words[bad], want[bad]))
+
+
+def config1_images():
+    y, x = np.mgrid[0:64, 0:64]
+    return [np.full((64, 64, 3), 128, np.uint8),
+            np.stack([(4 * x) & 255, (4 * y) & 255, (2 * (x + y)) & 255], axis=-1).astype(np.uint8),
+            np.random.default_rng(1).integers(0, 256, (64, 64, 3), dtype=np.uint8)]
+
+
+def test_config1_64x64_raster(enc):
+    for rgb in config1_images():
+        words, res = enc.encode(rgb)
+        assert_same(words, res, rgb)
+    words, res = enc.encode(config1_images()[0])
+    pat = [0x28A28A28, 0xA28A28A2, 0x8A28A28A]
+    assert list(words) == [pat[i % 3] for i in range(36)] and int(res["tail_bits"]) == 0
+
+
+def test_config1_64x64_through_the_port_protocol(enc):
+    pkg = load_pkg()
+    for rgb in config1_images():
+        enc.reset()
+        enc.push_pixels(pkg.raster_to_port_order(rgb))
+        words, res = enc.end_of_file()
+        want, r = O.encode(rgb)
+        assert np.array_equal(words, want)
+        assert (res.n_full_words, res.tail_bits, res.tail_word, res.eof_partial_ready) == \
+               (r.n_full_words, r.tail_bits, r.tail_word, r.eof_partial_ready)
+    # pixel-at-a-time, and protocol errors
+    rgb = config1_images()[2][:8, :16]
+    enc.reset()
+    for d in pkg.raster_to_port_order(rgb):
+        enc.push_pixel(int(d))
+    words, res = enc.end_of_file()
+    assert np.array_equal(words, O.encode(rgb)[0])
+    with pytest.raises(pkg.JpegEncError):
+        enc.push_pixel(0)  # rst required after end_of_file
+    enc.reset()
+    words, res = enc.end_of_file()  # nothing pushed: nothing comes out
+    assert len(words) == 0 and res.n_full_words == 0 and res.tail_bits == 0
+
+
+@pytest.mark.parametrize("hw", [(8, 8), (8, 16), (16, 8), (24, 40), (8, 512), (8, 520), (72, 72), (128, 8), (200, 328)])
+def test_ragged_sizes_random(enc, hw):
+    # covers: a single MCU, partial chunks, chunks wrapping over block rows, one-MCU-wide images
+    h, w = hw
+    rgb = np.random.default_rng(h * 1000 + w).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    words, res = enc.encode(rgb)
+    assert_same(words, res, rgb)
+
+
+def test_natural_and_noise_1080p(enc):
+    rgb = natural_like(1080, 1920, 2)
+    words, res = enc.encode(rgb)
+    assert_same(words, res, rgb)
+    rgb = np.random.default_rng(3).integers(0, 256, (1080, 1920, 3), dtype=np.uint8)
+    words, res = enc.encode(rgb)
+    assert_same(words, res, rgb)
+    assert int(res["total_bytes_stuffed"]) > int(res["total_bits_unstuffed"]) // 8  # 0xFF bytes were stuffed
+
+
+def test_extreme_patterns_take_the_long_string_path(enc):
+    # 0/255 noise produces the longest codes: some MCUs exceed the 63-word fast-path capacity
+    rng = np.random.default_rng(7)
+    rgb = rng.choice(np.array([0, 255], dtype=np.uint8), size=(64, 256, 3))
+    words, res = enc.encode(rgb)
+    assert_same(words, res, rgb)
+    assert int(res["total_bits_unstuffed"]) > 64 * 256 // 64 * 2016  # average above the fast-path capacity
+    # mixed: only a few long MCUs inside otherwise smooth content
+    rgb2 = natural_like(64, 256, 5)
+    rgb2[8:24, 40:72] = rgb[8:24, 40:72]
+    words, res = enc.encode(rgb2)
+    assert_same(words, res, rgb2)
+    # saturated colours hit the 8-bit wrap of the colour rounder
+    for ch in (0, 2):
+        rgb3 = np.zeros((16, 64, 3), np.uint8)
+        rgb3[..., ch] = 255
+        words, res = enc.encode(rgb3)
+        assert_same(words, res, rgb3)
+    y, x = np.mgrid[0:32, 0:64]
+    chk = (((x + y) & 1) * 255).astype(np.uint8)[..., None].repeat(3, -1)
+    words, res = enc.encode(chk)
+    assert_same(words, res, chk)
+
+
+def test_quirk_switches_and_quant_tables():
+    pkg = load_pkg()
+    rng = np.random.default_rng(9)
+    rgb = natural_like(64, 96, 3)
+    rgb[:8, :8, 0], rgb[:8, :8, 1], rgb[:8, :8, 2] = 0, 0, 255  # pure blue block
+    noise = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    qt = [rng.integers(1, 64, 64), rng.integers(1, 100, 64), np.full(64, 16)]
+    qt[0][5] = 0
+    sparse = [np.full(64, 255) for _ in range(3)]
+    for c in range(3):
+        sparse[c][rng.integers(0, 64, 6)] = rng.integers(1, 8, 6)
+    cases = [dict(), dict(rgb_wrap=False), dict(cb_6d64=False), dict(qtabs=qt), dict(qtabs=sparse),
+             dict(qtabs=sparse, cb_6d64=False)]
+    for kw in cases:
+        with pkg.JpegTop(**kw) as e:
+            cfg = O.default_config(qtabs=kw.get("qtabs"), rgb_wrap=kw.get("rgb_wrap", True),
+                                   cb_6d64=kw.get("cb_6d64", True))
+            for img in (rgb, noise):
+                words, res = e.encode(img)
+                assert_same(words, res, img, cfg)
+
+
+def test_batch_and_stripes(enc):
+    rng = np.random.default_rng(21)
+    imgs = np.stack([natural_like(72, 136, 30 + i) for i in range(5)] +
+                    [rng.integers(0, 256, (72, 136, 3), dtype=np.uint8)])
+    words, res = enc.encode_batch(imgs)
+    for i in range(len(imgs)):
+        assert_same(words[i], res[i], imgs[i])
+    # small workspace: forces several sub-batches
+    enc.set_workspace_limit(64 * 156 * 4 * 3 * 2)
+    words2, res2 = enc.encode_batch(imgs)
+    enc.set_workspace_limit(4 << 30)
+    for a, b in zip(words, words2):
+        assert np.array_equal(a, b)
+    assert res.tobytes() == res2.tobytes()
+    # stripes: each stripe is the encoding of that sub-image after rst
+    big = natural_like(128, 264, 77)
+    words, res = enc.encode_stripes(big, 4)
+    for s in range(4):
+        assert_same(words[s], res[s], big[32 * s:32 * (s + 1)])
+
+
+def test_output_too_small_is_reported_not_overrun(enc):
+    pkg = load_pkg()
+    rgb = np.random.default_rng(5).integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    want, r = O.encode(rgb)
+    cap = len(want) // 2
+    lib = enc.lib
+    words = np.full(cap + 16, 0xDEADBEEF, dtype=np.uint32)
+    res = np.zeros(1, dtype=pkg.RESULT_DTYPE)
+    rc = lib.jpegenc_encode_rgb8(enc._ctx, rgb.ctypes.data, 64, 64, 64 * 3, pkg.HOST_PTRS, words.ctypes.data, cap,
+                                 res.ctypes.data)
+    assert rc == pkg.E_TOO_SMALL
+    assert int(res[0]["status"]) == pkg.E_TOO_SMALL
+    assert int(res[0]["n_full_words"]) == r.n_full_words  # the size needed is still reported
+    assert np.array_equal(words[:cap], want[:cap])
+    assert (words[cap:] == 0xDEADBEEF).all()
+    # bad dimensions
+    assert lib.jpegenc_encode_rgb8(enc._ctx, rgb.ctypes.data, 60, 64, 180, 0, words.ctypes.data, cap,
+                                   res.ctypes.data) == pkg.E_BAD_ARG
+    assert lib.jpegenc_encode_rgb8(enc._ctx, rgb.ctypes.data, 64, 64, 100, 0, words.ctypes.data, cap,
+                                   res.ctypes.data) == pkg.E_BAD_ARG
+
+
+def test_device_pointers_strides_and_alignment():
+    torch = pytest.importorskip("torch")
+    pkg = load_pkg()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(13)
+    h, w, n = 40, 104, 3
+    imgs = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    cap = pkg.max_words(w, h)
+    with pkg.JpegTop(stream=torch.cuda.current_stream().cuda_stream) as e:
+        for pad, shift in ((0, 0), (8, 0), (4, 4), (5, 1), (3, 3)):
+            stride = w * 3 + pad
+            istride = stride * h + (16 if shift == 0 else 7)
+            buf = np.zeros(shift + istride * n + 64, dtype=np.uint8)
+            for i in range(n):
+                for r in range(h):
+                    o = shift + i * istride + r * stride
+                    buf[o:o + w * 3] = imgs[i, r].reshape(-1)
+            d_in = torch.from_numpy(buf).to(dev)
+            d_words = torch.zeros((n, cap), dtype=torch.int32, device=dev)
+            d_res = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
+            e.encode_batch_device(d_in.data_ptr() + shift, n, w, h, stride, istride, d_words.data_ptr(), cap,
+                                  d_res.data_ptr())
+            torch.cuda.synchronize()
+            res = d_res.cpu().numpy().view(pkg.RESULT_DTYPE).reshape(n)
+            words = d_words.cpu().numpy().view(np.uint32)
+            for i in range(n):
+                k = int(res[i]["n_full_words"]) + (1 if res[i]["tail_bits"] else 0)
+                assert_same(words[i, :k], res[i], imgs[i])
+
+
+def test_4k_batch_properties():
+    """Config-2 shape (3840x2160 frames, device resident) at a bounded count: two frames are checked
+    word for word against the oracle, the rest through size-independent properties -- equal images give
+    equal streams wherever they sit in the batch, no 0xFF byte is left unstuffed, and the bit count
+    equals the oracle's coefficient-domain count."""
+    torch = pytest.importorskip("torch")
+    pkg = load_pkg()
+    dev = torch.device("cuda:0")
+    h, w, n = 2160, 3840, 6
+    base = [natural_like(h, w, 100), np.random.default_rng(101).integers(0, 256, (h, w, 3), dtype=np.uint8)]
+    order = [0, 1, 0, 0, 1, 0]
+    d_in = torch.stack([torch.from_numpy(base[k]) for k in order]).to(dev)
+    cap = pkg.max_words(w, h) // 3
+    d_words = torch.zeros((n, cap), dtype=torch.int32, device=dev)
+    d_res = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
+    with pkg.JpegTop(stream=torch.cuda.current_stream().cuda_stream) as e:
+        e.encode_batch_device(d_in.data_ptr(), n, w, h, w * 3, h * w * 3, d_words.data_ptr(), cap, d_res.data_ptr())
+        torch.cuda.synchronize()
+    res = d_res.cpu().numpy().view(pkg.RESULT_DTYPE).reshape(n)
+    words = d_words.cpu().numpy().view(np.uint32)
+    for k in (0, 1):
+        i = order.index(k)
+        cnt = int(res[i]["n_full_words"]) + (1 if res[i]["tail_bits"] else 0)
+        assert_same(words[i, :cnt], res[i], base[k])
+        by = words[i, :cnt].astype(">u4").tobytes()[:int(res[i]["total_bytes_stuffed"])]
+        a = np.frombuffer(by, dtype=np.uint8)
+        ff = np.nonzero(a[:-1] == 0xFF)[0]
+        assert (a[ff + 1] == 0).all()
+    for i, k in enumerate(order):
+        j = order.index(k)
+        assert res[i].tobytes() == res[j].tobytes()
+        cnt = int(res[i]["n_full_words"]) + 1
+        assert np.array_equal(words[i, :cnt], words[j, :cnt])
