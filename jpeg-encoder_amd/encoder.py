@@ -61,6 +61,14 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
+    # PyTorch-ROCm wheels bundle their own HIP/HSA runtime under the same sonames as /opt/rocm.  Two
+    # runtimes in one process do not both see the GPU, so when torch is installed let it load its copy
+    # first: libjpegenc.so's NEEDED libamdhip64.so.7 then binds to that one and device pointers,
+    # streams and events are shared with torch.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(path or LIB_PATH)
     vp, sz, i32, u32 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint32
     L.jpegenc_default_config.argtypes = [C.POINTER(Config)]
