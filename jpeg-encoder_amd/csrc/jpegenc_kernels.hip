@@ -23,6 +23,10 @@
 #include "jpegenc_internal.h"
 #include "jpegenc_tables.h"
 
+#ifndef JPEGENC_SCHED_GROUP
+#define JPEGENC_SCHED_GROUP 4
+#endif
+
 namespace jpegenc {
 
 // ------------------------------------------------------------------------------------------------
@@ -57,19 +61,28 @@ __device__ constexpr uint8_t kZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 
 // `bias` to y_1..7 so that the rounding "bits above n plus the bit below" becomes one arithmetic shift.
 // All operands fit 24 bits (|x| <= 5792, |T| <= 8035), so the 24-bit multiplier is exact.
 // ------------------------------------------------------------------------------------------------
+// acc + a * coef with the 24-bit multiplier.  Written as one instruction so that each output is a
+// chain of fused multiply-adds: left to itself the compiler materialises all 28 products of a
+// transform first and spills them.
+__device__ __forceinline__ int mad24(int a, int coef, int acc) {
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(coef), "v"(acc));
+    return r;
+}
+
 __device__ __forceinline__ void dct8(int& x0, int& x1, int& x2, int& x3, int& x4, int& x5, int& x6, int& x7,
                                      int bias0, int bias, int sh) {
     const int s0 = x0 + x7, s1 = x1 + x6, s2 = x2 + x5, s3 = x3 + x4;
     const int d0 = x0 - x7, d1 = x1 - x6, d2 = x2 - x5, d3 = x3 - x4;
     const int e0 = s0 + s3, e1 = s1 + s2, f0 = s0 - s3, f1 = s1 - s2;
-    const int y0 = __mul24(5793, e0 + e1) + bias0;
-    const int y4 = __mul24(5793, e0 - e1) + bias;
-    const int y2 = __mul24(7568, f0) + __mul24(3135, f1) + bias;
-    const int y6 = __mul24(3135, f0) - __mul24(7568, f1) + bias;
-    const int y1 = __mul24(8035, d0) + __mul24(6811, d1) + __mul24(4551, d2) + __mul24(1598, d3) + bias;
-    const int y3 = __mul24(6811, d0) - __mul24(1598, d1) - __mul24(8035, d2) - __mul24(4551, d3) + bias;
-    const int y5 = __mul24(4551, d0) - __mul24(8035, d1) + __mul24(1598, d2) + __mul24(6811, d3) + bias;
-    const int y7 = __mul24(1598, d0) - __mul24(4551, d1) + __mul24(6811, d2) - __mul24(8035, d3) + bias;
+    const int y0 = mad24(e0 + e1, 5793, bias0);
+    const int y4 = mad24(e0 - e1, 5793, bias);
+    const int y2 = mad24(f1, 3135, mad24(f0, 7568, bias));
+    const int y6 = mad24(f1, -7568, mad24(f0, 3135, bias));
+    const int y1 = mad24(d3, 1598, mad24(d2, 4551, mad24(d1, 6811, mad24(d0, 8035, bias))));
+    const int y3 = mad24(d3, -4551, mad24(d2, -8035, mad24(d1, -1598, mad24(d0, 6811, bias))));
+    const int y5 = mad24(d3, 6811, mad24(d2, 1598, mad24(d1, -8035, mad24(d0, 4551, bias))));
+    const int y7 = mad24(d3, -8035, mad24(d2, 6811, mad24(d1, -4551, mad24(d0, 1598, bias))));
     x0 = y0 >> sh; x1 = y1 >> sh; x2 = y2 >> sh; x3 = y3 >> sh;
     x4 = y4 >> sh; x5 = y5 >> sh; x6 = y6 >> sh; x7 = y7 >> sh;
 }
@@ -84,21 +97,31 @@ __device__ __forceinline__ int sext11(int v) { return (v << 21) >> 21; }
 // the RTL (25-bit pass-1 snapshots, 13/11-bit B) cannot trigger for 8-bit inputs: |A| < 2^24 and
 // |B| <= 1448 resp. 363; the 25-/32-bit Z registers are taken modulo 2^32 here and only bits below
 // bit 27 are used.
-__device__ __forceinline__ void dct8x8(int (&x)[64], bool luma) {
-    const int sh1 = luma ? 12 : 14;
-    const int sh2 = luma ? 16 : 14;
-    const int b1 = 1 << (sh1 - 1);
-    const int b2 = 1 << (sh2 - 1);
-#pragma unroll
-    for (int r = 0; r < 8; ++r)
-        dct8(x[r * 8 + 0], x[r * 8 + 1], x[r * 8 + 2], x[r * 8 + 3], x[r * 8 + 4], x[r * 8 + 5], x[r * 8 + 6],
-             x[r * 8 + 7], b1 - JPEGENC_DCT_LEVEL_SHIFT, b1, sh1);
+template <bool LUMA>
+struct DctK {
+    // compile-time shifts: luma rounds at bit 12 then 16, chroma at bit 14 twice
+    static constexpr int sh1 = LUMA ? 12 : 14;
+    static constexpr int sh2 = LUMA ? 16 : 14;
+    static constexpr int b1 = 1 << (sh1 - 1);
+    static constexpr int b2 = 1 << (sh2 - 1);
+};
+
+// pass 1 on one row of samples (in place): x[r][c] -> B[r][k]
+template <bool LUMA>
+__device__ __forceinline__ void dct_row(int (&x)[64], int r) {
+    dct8(x[r * 8 + 0], x[r * 8 + 1], x[r * 8 + 2], x[r * 8 + 3], x[r * 8 + 4], x[r * 8 + 5], x[r * 8 + 6],
+         x[r * 8 + 7], DctK<LUMA>::b1 - JPEGENC_DCT_LEVEL_SHIFT, DctK<LUMA>::b1, DctK<LUMA>::sh1);
+}
+
+// pass 2 on all columns (in place): B[r][k] -> F[j][k], then the 11-bit output ports (cb_dct.sv:20-35)
+template <bool LUMA>
+__device__ __forceinline__ void dct_cols(int (&x)[64]) {
 #pragma unroll
     for (int k = 0; k < 8; ++k)
         dct8(x[0 * 8 + k], x[1 * 8 + k], x[2 * 8 + k], x[3 * 8 + k], x[4 * 8 + k], x[5 * 8 + k], x[6 * 8 + k],
-             x[7 * 8 + k], b2, b2, sh2);
+             x[7 * 8 + k], DctK<LUMA>::b2, DctK<LUMA>::b2, DctK<LUMA>::sh2);
 #pragma unroll
-    for (int i = 0; i < 64; ++i) x[i] = sext11(x[i]);  // 11-bit output ports (cb_dct.sv:20-35)
+    for (int i = 0; i < 64; ++i) x[i] = sext11(x[i]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -109,16 +132,18 @@ struct BitWriter {
     uint32_t cur;   // pending bits (low n bits valid)
     uint32_t n;     // 0..31
     uint32_t wp;    // next LDS word index
-    uint32_t wlim;  // first LDS word index this lane may not write
+    uint32_t wlim;  // first LDS word index this lane may not fill; doubles as its dump slot
 };
 
+// Branch-free: the store always happens; when no word completes (or the region is full) it goes to the
+// lane's dump slot at wlim.  Shift counts are masked because they are out of range exactly when the
+// value is not used.
 __device__ __forceinline__ void bw_emit(BitWriter& s, uint32_t bits, uint32_t len, uint32_t* priv) {
-    const uint32_t t = s.n + len;  // len <= 26, so t < 64 and a flush implies n >= 6
-    if (t >= 32) {
-        const uint32_t word = (s.cur << (32u - s.n)) | (bits >> (t - 32u));
-        if (s.wp < s.wlim) priv[s.wp] = word;
-        s.wp += 1;
-    }
+    const uint32_t t = s.n + len;  // len <= 26, so t < 64 and a completed word implies n >= 6
+    const uint32_t word = (s.cur << ((32u - s.n) & 31u)) | (bits >> ((t - 32u) & 31u));
+    const uint32_t at = (t >= 32u) ? min(s.wp, s.wlim) : s.wlim;
+    priv[at] = word;
+    s.wp += t >> 5;
     s.cur = (s.cur << len) | bits;
     s.n = t & 31u;
 }
@@ -177,6 +202,9 @@ __device__ __forceinline__ void encode_block(const int (&blk)[64], int dc_pred, 
         const uint32_t ent = htab[emit ? (r4 | size) : (uint32_t)kNullSym];
         bw_emit(bw, (ent >> 5) | amp, ent & 31u, priv);
         r4 = nz ? 0u : ((r4 + 16u) & 0xF0u);
+        // bound how far the scheduler may hoist the (independent) size/amplitude work of later
+        // coefficients: unbounded, it makes all 63 live at once and spills
+        if ((k % JPEGENC_SCHED_GROUP) == 0) __builtin_amdgcn_sched_barrier(0);
     }
     {
         const int v = blk[63];
@@ -292,9 +320,6 @@ __global__ __launch_bounds__(64, 2) void k_encode_chunks(EncodeParams p) {
     const uint8_t* img_base = p.rgb + (int64_t)img * p.image_stride;
     const uint8_t* src = img_base + (int64_t)by * 8 * p.stride + (int64_t)bx * 24;
 
-    uint32_t raw[48];
-    load_mcu<ALIGN>(src, p.stride, raw);
-
     // DC predictors for lane 0: the MCU just before this chunk (0 at the start of an image: rst)
     int halo[3] = {0, 0, 0};
     if (c > 0) {
@@ -326,20 +351,46 @@ __global__ __launch_bounds__(64, 2) void k_encode_chunks(EncodeParams p) {
         BitWriter bw;
         bw.cur = 0;
         bw.n = 0;
-        bw.wp = base;
-        bw.wlim = active ? base + cap : base;
+        // usable words [base, base+cap), dump slot base+cap; lanes of other groups count their bits but
+        // only ever store to the spare last word of the region
+        const uint32_t wp0 = active ? base : base + stride - 1u;
+        bw.wp = wp0;
+        bw.wlim = active ? base + cap : wp0;
 
 #pragma unroll 1
         for (int comp = 0; comp < 3; ++comp) {
             const CompCoef cc = comp_coef(comp);
             int x[64];
+            // The MCU's 192 bytes are re-read for every component (served by L2 after the first pass):
+            // holding them in 48 registers across the whole chunk costs more occupancy than the reloads.
+            uint32_t raw[48];
+            load_mcu<ALIGN>(src, p.stride, raw);
+            // Two separately compiled bodies (shifts are immediates).  The differing asm comments keep
+            // the optimiser from folding them back into one body with run-time shift counts.  Each row
+            // is converted and transformed before the next one is touched, so the raw pixels die early.
+            if (comp == 0) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
+                for (int r = 0; r < 8; ++r) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    x[r * 8 + q] = colour(raw_byte(raw, r, 3 * q), raw_byte(raw, r, 3 * q + 1), raw_byte(raw, r, 3 * q + 2),
-                                          cc.k0, cc.cr, cc.cg, cc.cb, rgb_wrap);
-            dct8x8(x, comp == 0);
+                    for (int q = 0; q < 8; ++q)
+                        x[r * 8 + q] = colour(raw_byte(raw, r, 3 * q), raw_byte(raw, r, 3 * q + 1),
+                                              raw_byte(raw, r, 3 * q + 2), cc.k0, cc.cr, cc.cg, cc.cb, rgb_wrap);
+                    dct_row<true>(x, r);
+                }
+                dct_cols<true>(x);
+                asm volatile("; luma dct done" ::: "memory");
+            } else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        x[r * 8 + q] = colour(raw_byte(raw, r, 3 * q), raw_byte(raw, r, 3 * q + 1),
+                                              raw_byte(raw, r, 3 * q + 2), cc.k0, cc.cr, cc.cg, cc.cb, rgb_wrap);
+                    dct_row<false>(x, r);
+                }
+                dct_cols<false>(x);
+                asm volatile("; chroma dct done" ::: "memory");
+            }
             if constexpr (QUANT) {
                 const int32_t* qm = p.qmul + comp * 64;
 #pragma unroll
@@ -351,10 +402,10 @@ __global__ __launch_bounds__(64, 2) void k_encode_chunks(EncodeParams p) {
             encode_block(x, pred, comp == 1 && cb_quirk, htab, priv, bw);
         }
         // flush the residual bits, left-aligned and zero-filled
-        if (bw.n != 0 && bw.wp < bw.wlim) priv[bw.wp] = bw.cur << (32u - bw.n);
+        if (active && bw.n != 0 && bw.wp < bw.wlim) priv[bw.wp] = bw.cur << (32u - bw.n);
         // Every lane counts its bits whether or not it may store them, so the first pass already knows
         // which tier the chunk needs.
-        const uint32_t Lall = valid ? ((bw.wp - base) * 32u + bw.n) : 0u;
+        const uint32_t Lall = valid ? ((bw.wp - wp0) * 32u + bw.n) : 0u;
         if (n_groups == 1 && __any((int)(Lall > cap * 32u))) {
             n_groups = __any((int)(Lall > (2u * kRegionWords - 2u) * 32u)) ? 4 : 2;
             g = -1;  // restart the chunk on that tier
