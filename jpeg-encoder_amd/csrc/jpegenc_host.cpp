@@ -13,22 +13,31 @@ using namespace jpegenc;
 
 namespace jpegenc {
 
-// entry = ((code << size) << 5) | (code_length + size); index (run<<4|size) for AC, 256+size for DC.
-// Code/length tables: T.81 K.4 (DC) and K.5 (AC) as hard-coded in rtl/4_huffman/cr_huff.sv:1553-2082.
+// Layout: see jpegenc_internal.h.  Code/length tables: T.81 K.4 (DC) and K.5 (AC) as hard-coded in
+// rtl/4_huffman/cr_huff.sv:1553-2082.  The RTL's map entries (run 1..14, size 0) -> table entry 0 are
+// reachable only by an AC coefficient of -1024 (size rule on bits [9:0]); coefficients computed from
+// 8-bit pixels satisfy |AC| <= 1021 (|B| <= 1448 luma / 363 chroma, row sums of |T| <= 46344), so on
+// this path a size-0 symbol always is a zero coefficient and those entries stay empty.
 void build_htab(uint32_t out[kHtabEntries]) {
     for (int i = 0; i < kHtabEntries; ++i) out[i] = 0;
-    for (int sym = 0; sym < 256; ++sym) {
-        const int idx = JPEGENC_AC_RUN_CODE[sym];
-        const int size = sym & 15;
-        if (idx == 0xFF || size > 10) continue;
-        const uint32_t code = JPEGENC_AC_CODE[idx];
-        const uint32_t len = JPEGENC_AC_LEN[idx];
-        out[sym] = ((code << size) << 5) | (len + size);
+    for (int eob = 0; eob < 2; ++eob)
+        for (int sym = 0; sym < 256; ++sym) {
+            const int idx = JPEGENC_AC_RUN_CODE[sym];
+            const int size = sym & 15;
+            if (idx == 0xFF || size > 10) continue;
+            if (size == 0 && (sym != JPEGENC_SYM_ZRL || eob)) continue;
+            const uint32_t code = JPEGENC_AC_CODE[idx];
+            const uint32_t len = JPEGENC_AC_LEN[idx];
+            out[eob * 256 + sym] = ((len + size) << 27) | (code << size);
+        }
+    {
+        const int idx = JPEGENC_AC_RUN_CODE[JPEGENC_SYM_EOB];
+        out[kHtabEob] = (uint32_t(JPEGENC_AC_LEN[idx]) << 27) | JPEGENC_AC_CODE[idx];
     }
     for (int s = 0; s < 12; ++s) {
         const uint32_t code = JPEGENC_DC_CODE[s];
         const uint32_t len = JPEGENC_DC_LEN[s];
-        out[kHtabDc + s] = ((code << s) << 5) | (len + s);
+        out[kHtabDc + s] = ((len + s) << 27) | (code << s);
     }
 }
 

@@ -16,11 +16,16 @@ constexpr int kMaxMcuWords = 156;
 // Chunk stream slot in the workspace, in 32-bit words: worst case of 64 MCUs.
 constexpr int kSlotWords = kChunkMcus * kMaxMcuWords;  // 9984 words = 39,936 B
 
-// Packed Huffman table: 256 AC entries indexed by (run << 4 | size), then 16 DC entries by size.
-// entry = ((code << size) << 5) | (code_length + size); 0 = nothing to emit.
-constexpr int kHtabEntries = 272;
-constexpr int kHtabDc = 256;
-constexpr int kNullSym = 0x0F;  // (run 0, size 15): never assigned, entry 0
+// Packed Huffman table in LDS: entry = (total_length << 27) | (code << size), total_length = code length
+// + amplitude bits; 0 = nothing to emit.
+//   [0, 512)   AC, index = eob << 8 | run << 4 | size.  (run <= 14, size 0) is a zero coefficient inside a
+//              run: nothing; (run 15, size 0) is the 16th zero: ZRL in the eob = 0 half, nothing in the
+//              eob = 1 half (rtl/4_huffman/cr_huff.sv:558).
+//   [512]      EOB
+//   [528, 540) DC by size
+constexpr int kHtabEntries = 544;
+constexpr int kHtabEob = 512;
+constexpr int kHtabDc = 528;
 
 struct EncodeParams {
     const uint8_t* rgb;    // first image of this launch

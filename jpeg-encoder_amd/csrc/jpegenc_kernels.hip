@@ -113,15 +113,15 @@ __device__ __forceinline__ void dct_row(int (&x)[64], int r) {
          x[r * 8 + 7], DctK<LUMA>::b1 - JPEGENC_DCT_LEVEL_SHIFT, DctK<LUMA>::b1, DctK<LUMA>::sh1);
 }
 
-// pass 2 on all columns (in place): B[r][k] -> F[j][k], then the 11-bit output ports (cb_dct.sv:20-35)
+// pass 2 on all columns (in place): B[r][k] -> F[j][k].  The 11-bit output ports (cb_dct.sv:20-35)
+// cannot wrap for 8-bit samples: DC lies in [-1024, 1016] and |AC| <= 1021 (|Z| <= 1448 * 46344 for
+// luma, 363 * 46344 for chroma, before the final shift).
 template <bool LUMA>
 __device__ __forceinline__ void dct_cols(int (&x)[64]) {
 #pragma unroll
     for (int k = 0; k < 8; ++k)
         dct8(x[0 * 8 + k], x[1 * 8 + k], x[2 * 8 + k], x[3 * 8 + k], x[4 * 8 + k], x[5 * 8 + k], x[6 * 8 + k],
              x[7 * 8 + k], DctK<LUMA>::b2, DctK<LUMA>::b2, DctK<LUMA>::sh2);
-#pragma unroll
-    for (int i = 0; i < 64; ++i) x[i] = sext11(x[i]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -151,21 +151,26 @@ __device__ __forceinline__ void bw_emit(BitWriter& s, uint32_t bits, uint32_t le
 // Huffman-codes one component block (coefficients in Huffman input order) into the lane's writer.
 // AC algorithm, lane-serial over the zig-zag order (cr_huff.sv:675-685 run counter, :656 forced run 0
 // at the last slot, :558 ZRL only when end_of_block is low, :518 the last slot always emits):
-//   non-zero v : symbol (run<<4)|size10(v), then the low size bits of v (v>=0) or v-1 (v<0)
+//   non-zero v : symbol (run<<4)|size(v), then the low size bits of v (v>=0) or v-1 (v<0)
 //   zero v     : ZRL iff the 4-bit run counter already holds 15 and end_of_block(k) is low
 //   k == 63    : zero -> EOB, non-zero -> ordinary symbol and no EOB
-// size10(v) = bit_length(|v| & 0x3FF): for v >= 0 the highest set bit of v[9:0], for v < 0 the highest
-// clear bit of (v-1)[9:0] (cr_huff.sv:1411-1486); ~(v-1) == -v makes the two cases one expression.
+// size(v) = bit_length(|v|): the RTL takes the highest set bit of v[9:0] for v >= 0 and the highest
+// clear bit of (v-1)[9:0] for v < 0 (cr_huff.sv:1411-1486); ~(v-1) == -v makes the two cases one
+// expression, and the restriction to bits [9:0] (resp. [10:0] for DC) only matters for values that
+// 8-bit pixels cannot produce (see build_htab).  The table lookup does the rest: the index carries
+// run, size and the end_of_block flag, and empty entries make a zero coefficient emit nothing.
+__device__ __forceinline__ uint32_t mag_bits(int v) { return 32u - (uint32_t)__clz(__builtin_abs(v)); }
+__device__ __forceinline__ uint32_t amp_bits(int v, uint32_t size) {
+    return __builtin_amdgcn_ubfe((uint32_t)(v + (v >> 31)), 0u, size);
+}
+
 __device__ __forceinline__ void encode_block(const int (&blk)[64], int dc_pred, bool cb_eob_quirk,
                                              const uint32_t* htab, uint32_t* priv, BitWriter& bw) {
-    // DC difference, 12 bit (cr_huff.sv:1317): |d| <= 2047 for 11-bit inputs, no wrap possible.
-    {
+    {   // DC difference, 12 bit (cr_huff.sv:1317): |d| <= 2047 for 11-bit inputs, no wrap possible
         const int d = blk[0] - dc_pred;
-        const uint32_t a = (uint32_t)__builtin_abs(d) & 0x7FFu;
-        const uint32_t size = 32u - (uint32_t)__clz((int)a);
-        const uint32_t amp = (uint32_t)(d + (d >> 31)) & ((1u << size) - 1u);
+        const uint32_t size = mag_bits(d);
         const uint32_t ent = htab[kHtabDc + size];
-        bw_emit(bw, (ent >> 5) | amp, ent & 31u, priv);
+        bw_emit(bw, (ent & 0x7FFFFFFu) | amp_bits(d, size), ent >> 27, priv);
     }
     // group-of-eight all-zero tests over zig-zag indices 16..63 (cr_huff.sv:190-204)
     int o2 = 0, o3 = 0, o4 = 0, o5 = 0, o6 = 0, o7 = 0;
@@ -180,39 +185,29 @@ __device__ __forceinline__ void encode_block(const int (&blk)[64], int dc_pred, 
     }
     const int t67 = o6 | o7;
     const int t47 = o4 | o5 | t67;
-    const bool eob_a = (o2 | o3 | t47) == 0;  // block_counter < 32
-    const bool eob_b = t47 == 0;              // block_counter < 48
+    // end_of_block as a table-index bit (256 = set), per block_counter range (cr_huff.sv:213-231)
+    const uint32_t eob_a = ((o2 | o3 | t47) == 0) ? 256u : 0u;  // block_counter < 32
+    const uint32_t eob_b = (t47 == 0) ? 256u : 0u;              // block_counter < 48
     // block_counter <= 64: groups 7,8 -- except in cb_huff, where `6'd64` is 0 and the branch that
     // sets end_of_block to 1 always wins (cb_huff.sv:238-243)
-    const bool eob_c = cb_eob_quirk || (t67 == 0);
+    const uint32_t eob_c = (cb_eob_quirk || t67 == 0) ? 256u : 0u;
 
     uint32_t r4 = 0;  // run << 4
 #pragma unroll
     for (int k = 1; k <= 62; ++k) {
         const int v = blk[kZZ[k]];
-        const uint32_t a = (uint32_t)__builtin_abs(v) & 0x3FFu;
-        const uint32_t size = 32u - (uint32_t)__clz((int)a);
-        const uint32_t amp = (uint32_t)(v + (v >> 31)) & ((1u << size) - 1u);
-        const bool nz = v != 0;
-        bool emit = nz;
-        if (k >= 16) {  // a run of 15 zeros cannot complete before k = 16
-            const bool eob = (k + 2 < 32) ? eob_a : (k + 2 < 48) ? eob_b : eob_c;
-            emit = nz || (r4 == 0xF0u && !eob);
-        }
-        const uint32_t ent = htab[emit ? (r4 | size) : (uint32_t)kNullSym];
-        bw_emit(bw, (ent >> 5) | amp, ent & 31u, priv);
-        r4 = nz ? 0u : ((r4 + 16u) & 0xF0u);
-        // bound how far the scheduler may hoist the (independent) size/amplitude work of later
-        // coefficients: unbounded, it makes all 63 live at once and spills
-        if ((k % JPEGENC_SCHED_GROUP) == 0) __builtin_amdgcn_sched_barrier(0);
+        const uint32_t size = mag_bits(v);
+        // a run of 15 zeros cannot complete before k = 16, so the flag only matters from there on
+        const uint32_t eob = (k < 16) ? 0u : (k + 2 < 32) ? eob_a : (k + 2 < 48) ? eob_b : eob_c;
+        const uint32_t ent = htab[r4 | size | eob];
+        bw_emit(bw, (ent & 0x7FFFFFFu) | amp_bits(v, size), ent >> 27, priv);
+        r4 = (v != 0) ? 0u : ((r4 + 16u) & 0xF0u);
     }
     {
         const int v = blk[63];
-        const uint32_t a = (uint32_t)__builtin_abs(v) & 0x3FFu;
-        const uint32_t size = 32u - (uint32_t)__clz((int)a);
-        const uint32_t amp = (uint32_t)(v + (v >> 31)) & ((1u << size) - 1u);
-        const uint32_t ent = htab[(v != 0) ? (r4 | size) : 0u];
-        bw_emit(bw, (ent >> 5) | amp, ent & 31u, priv);
+        const uint32_t size = mag_bits(v);
+        const uint32_t ent = htab[(v != 0) ? (r4 | size) : (uint32_t)kHtabEob];
+        bw_emit(bw, (ent & 0x7FFFFFFu) | amp_bits(v, size), ent >> 27, priv);
     }
 }
 
@@ -249,11 +244,16 @@ __device__ __forceinline__ uint32_t raw_byte(const uint32_t (&raw)[48], int r, i
 
 // One colour component of one pixel (rgb2ycrcb.sv:77-91 sums, :105-135 rounding).  k0 carries the
 // +2^21 offset of Cb/Cr and the rounding bit 2^13.  The 22-bit sums are never negative, so the
-// arithmetic shift is the RTL's bit slice; `& 0xFF` is the 8-bit wrap of the rounder (255 + 1 -> 0).
-__device__ __forceinline__ int colour(uint32_t R, uint32_t G, uint32_t B, int k0, int cr, int cg, int cb, bool wrap) {
+// arithmetic shift is the RTL's bit slice.  The rounded value is 0..256; 256 is reachable only by Cb and
+// Cr (pure blue / pure red).  MODE 0: luma, no fix-up needed; MODE 1: chroma as written, the 8-bit
+// rounder wraps 256 to 0 and the clamp is dead code; MODE 2: chroma with the clamp working.
+template <int MODE>
+__device__ __forceinline__ int colour(uint32_t R, uint32_t G, uint32_t B, int k0, int cr, int cg, int cb) {
     const int s = k0 + __mul24(cr, (int)R) + __mul24(cg, (int)G) + __mul24(cb, (int)B);
     const int v = s >> 14;
-    return wrap ? (v & 0xFF) : min(v, 255);
+    if constexpr (MODE == 0) return v;
+    if constexpr (MODE == 1) return v & 0xFF;
+    return min(v, 255);
 }
 
 struct CompCoef {
@@ -299,7 +299,7 @@ __device__ __forceinline__ int halo_dc(int sample, bool luma, int qm0, bool do_q
 constexpr int kRegionWords = 65;
 constexpr int kPrivWords = 64 * kRegionWords;  // 4160 words = 16,640 B
 
-template <int ALIGN, bool QUANT>
+template <int ALIGN, bool QUANT, bool WRAP>
 __global__ __launch_bounds__(64, 2) void k_encode_chunks(EncodeParams p) {
     __shared__ uint32_t priv[kPrivWords];
     __shared__ uint32_t htab[kHtabEntries];
@@ -307,7 +307,6 @@ __global__ __launch_bounds__(64, 2) void k_encode_chunks(EncodeParams p) {
     const uint32_t gid = blockIdx.x;
     const uint32_t img = gid / p.cpi;
     const uint32_t c = gid - img * p.cpi;
-    const bool rgb_wrap = (p.flags & 1u) != 0;
     const bool cb_quirk = (p.flags & 2u) != 0;
 
     for (int i = lane; i < kHtabEntries; i += 64) htab[i] = p.htab[i];
@@ -330,7 +329,8 @@ __global__ __launch_bounds__(64, 2) void k_encode_chunks(EncodeParams p) {
 #pragma unroll
         for (int comp = 0; comp < 3; ++comp) {
             const CompCoef cc = comp_coef(comp);
-            const int smp = colour(R, G, B, cc.k0, cc.cr, cc.cg, cc.cb, rgb_wrap);
+            int smp = colour<0>(R, G, B, cc.k0, cc.cr, cc.cg, cc.cb);
+            if (comp != 0) smp = WRAP ? (smp & 0xFF) : min(smp, 255);
             halo[comp] = halo_dc(smp, comp == 0, QUANT ? p.qmul[comp * 64] : 4096, QUANT);
         }
     }
@@ -373,8 +373,8 @@ __global__ __launch_bounds__(64, 2) void k_encode_chunks(EncodeParams p) {
                 for (int r = 0; r < 8; ++r) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q)
-                        x[r * 8 + q] = colour(raw_byte(raw, r, 3 * q), raw_byte(raw, r, 3 * q + 1),
-                                              raw_byte(raw, r, 3 * q + 2), cc.k0, cc.cr, cc.cg, cc.cb, rgb_wrap);
+                        x[r * 8 + q] = colour<0>(raw_byte(raw, r, 3 * q), raw_byte(raw, r, 3 * q + 1),
+                                                 raw_byte(raw, r, 3 * q + 2), cc.k0, cc.cr, cc.cg, cc.cb);
                     dct_row<true>(x, r);
                 }
                 dct_cols<true>(x);
@@ -384,8 +384,8 @@ __global__ __launch_bounds__(64, 2) void k_encode_chunks(EncodeParams p) {
                 for (int r = 0; r < 8; ++r) {
 #pragma unroll
                     for (int q = 0; q < 8; ++q)
-                        x[r * 8 + q] = colour(raw_byte(raw, r, 3 * q), raw_byte(raw, r, 3 * q + 1),
-                                              raw_byte(raw, r, 3 * q + 2), cc.k0, cc.cr, cc.cg, cc.cb, rgb_wrap);
+                        x[r * 8 + q] = colour<WRAP ? 1 : 2>(raw_byte(raw, r, 3 * q), raw_byte(raw, r, 3 * q + 1),
+                                                            raw_byte(raw, r, 3 * q + 2), cc.k0, cc.cr, cc.cg, cc.cb);
                     dct_row<false>(x, r);
                 }
                 dct_cols<false>(x);
@@ -416,9 +416,14 @@ __global__ __launch_bounds__(64, 2) void k_encode_chunks(EncodeParams p) {
         __syncthreads();  // strings visible to all lanes
 
         // ---- concatenate the group's strings in place, in lane order, at LDS word 0 -------------
+        // One source string per step, all 64 lanes moving one word each.  Destination word d0+t is
+        // (src[t-1]:src[t]) >> s; src[t-1] comes from the neighbouring lane, the bits a string shares
+        // with its predecessor's last word travel in `tailw` (wave-uniform).  In place is safe because a
+        // string never moves to a higher address and all reads of a step precede its writes.
         uint32_t gtotal;
         const uint32_t off = wave_excl_scan_u32(L, lane, &gtotal);
         const int first = g * lanes_per_group;
+        uint32_t tailw = 0;
         for (int m = 0; m < lanes_per_group; ++m) {
             const int M = first + m;
             const uint32_t LM = readlane_u32(L, M);
@@ -426,17 +431,31 @@ __global__ __launch_bounds__(64, 2) void k_encode_chunks(EncodeParams p) {
             const uint32_t oM = readlane_u32(off, M);
             const uint32_t bM = (uint32_t)m * stride;
             const uint32_t s = oM & 31u, d0 = oM >> 5;
-            const uint32_t nw = (LM + 31u) >> 5;          // source words
-            const uint32_t nd = (s + LM + 31u) >> 5;      // destination words touched
-            for (uint32_t t0 = 0; t0 < nd; t0 += 64) {
-                const uint32_t t = t0 + lane;
+            const uint32_t nw = (LM + 31u) >> 5;      // source words
+            const uint32_t nd = (s + LM + 31u) >> 5;  // destination words touched
+            if (nd <= 64u) {
+                const uint32_t t = lane;
                 const uint32_t lo = (t < nw) ? priv[bM + t] : 0u;
-                const uint32_t hi = (t >= 1 && t - 1 < nw) ? priv[bM + t - 1] : 0u;
-                uint32_t w = s ? ((hi << (32u - s)) | (lo >> s)) : lo;
-                const uint32_t old = (t == 0 && s) ? priv[d0] : 0u;  // bits of the previous strings
-                __syncthreads();  // all reads of this round before its writes
-                if (t < nd) priv[d0 + t] = w | old;
+                uint32_t hi = __shfl_up(lo, 1);
+                if (t == 0) hi = 0u;
+                uint32_t w = __builtin_amdgcn_alignbit(hi, lo, s);
+                if (t == 0) w |= tailw;
+                __syncthreads();  // all reads of this step before its writes
+                if (t < nd) priv[d0 + t] = w;
+                tailw = ((s + LM) & 31u) ? readlane_u32(w, (int)nd - 1) : 0u;
                 __syncthreads();
+            } else {
+                for (uint32_t t0 = 0; t0 < nd; t0 += 64) {
+                    const uint32_t t = t0 + lane;
+                    const uint32_t lo = (t < nw) ? priv[bM + t] : 0u;
+                    const uint32_t hi = (t >= 1 && t - 1 < nw) ? priv[bM + t - 1] : 0u;
+                    uint32_t w = __builtin_amdgcn_alignbit(hi, lo, s);
+                    if (t == 0) w |= tailw;
+                    __syncthreads();
+                    if (t < nd) priv[d0 + t] = w;
+                    if (t0 + 64 >= nd) tailw = ((s + LM) & 31u) ? readlane_u32(w, (int)(nd - 1 - t0)) : 0u;
+                    __syncthreads();
+                }
             }
         }
 
@@ -650,13 +669,18 @@ __global__ __launch_bounds__(64) void k_stuff(StuffParams p) {
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+template <int ALIGN, bool QUANT>
+static hipError_t launch_encode_b(const EncodeParams& p, uint32_t grid, hipStream_t s) {
+    if (p.flags & 1u)
+        hipLaunchKernelGGL((k_encode_chunks<ALIGN, QUANT, true>), dim3(grid), dim3(64), 0, s, p);
+    else
+        hipLaunchKernelGGL((k_encode_chunks<ALIGN, QUANT, false>), dim3(grid), dim3(64), 0, s, p);
+    return hipGetLastError();
+}
+
 template <int ALIGN>
 static hipError_t launch_encode_a(const EncodeParams& p, uint32_t grid, hipStream_t s) {
-    if (p.qmul)
-        hipLaunchKernelGGL((k_encode_chunks<ALIGN, true>), dim3(grid), dim3(64), 0, s, p);
-    else
-        hipLaunchKernelGGL((k_encode_chunks<ALIGN, false>), dim3(grid), dim3(64), 0, s, p);
-    return hipGetLastError();
+    return p.qmul ? launch_encode_b<ALIGN, true>(p, grid, s) : launch_encode_b<ALIGN, false>(p, grid, s);
 }
 
 hipError_t launch_encode(const EncodeParams& p, uint32_t n_images, int align, hipStream_t s) {
