@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_stuff: one wavefront per chunk.
+// k_stuff: one wavefront per chunk, 16 stream bytes per lane and step.
 // The image's unstuffed stream is the concatenation of its chunk streams; chunk c covers global bits
 // [o, o+n).  A byte of that stream is owned by the chunk holding its last bit, so chunk c owns bytes
 // [o>>3, (o+n)>>3): its first byte may begin in the previous chunk (every chunk has >= 1152 bits, so
@@ -525,10 +525,23 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams p) {
 // after them (ff_checker.sv:96-179).  Output byte i of the stuffed stream lives in word i/4 at bits
 // 31-8*(i%4), i.e. at byte address i^3 of a little-endian word array.
 // ------------------------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(4))) Words4 {
+    uint32_t w[4];
+};
+
+// bit 7 of every byte of the result is set iff that byte of v is 0xFF
+__device__ __forceinline__ uint32_t ff_mask(uint32_t v) {
+    uint32_t a = v & (v << 4);
+    a &= a << 2;
+    a &= a << 1;
+    return a & 0x80808080u;
+}
+
+constexpr int kStageBytes = 2048 + 64;  // one step: <= 1024 bytes, doubled by stuffing, + residual
+
 template <bool WRITE>
 __global__ __launch_bounds__(64) void k_stuff(StuffParams p) {
-    __shared__ uint32_t ring_w[256];  // 1 KiB window of the stuffed byte stream, byte i at (i & 1023) ^ 3
-    uint8_t* ring = reinterpret_cast<uint8_t*>(ring_w);
+    __shared__ __attribute__((aligned(16))) uint8_t stage[WRITE ? kStageBytes : 16];
     const int lane = threadIdx.x;
     const uint32_t gid = blockIdx.x;
     const uint32_t img = gid / p.cpi;
@@ -537,9 +550,9 @@ __global__ __launch_bounds__(64) void k_stuff(StuffParams p) {
     const uint64_t o = p.bit_off[gid];
     const uint32_t* S = p.slots + (uint64_t)gid * kSlotWords;
 
-    // last 32 bits of the predecessor's stream (it has >= 1152 bits)
+    // last 32 bits of the predecessor's stream (it has >= 1152 bits): stands in for word -1
     uint32_t pw = 0;
-    if (c > 0) {
+    if (c > 0 && (o & 7u)) {
         const uint32_t np = p.chunk_bits[gid - 1];
         const uint32_t* Sp = S - kSlotWords;
         const uint32_t l = np - 32u, wi = l >> 5, s = l & 31u;
@@ -549,70 +562,112 @@ __global__ __launch_bounds__(64) void k_stuff(StuffParams p) {
     const uint64_t q_first = o >> 3;
     const uint64_t q_end = (o + n) >> 3;
     const uint32_t nbytes = (uint32_t)(q_end - q_first);
-    const int lstart = -(int)(o & 7u);  // local bit position of the first owned byte
-
-    auto fetch32 = [&](int l) -> uint32_t {  // 32 stream bits starting at local bit l (l >= -7)
-        const int wi = l >> 5;
-        const uint32_t s = (uint32_t)l & 31u;
-        const uint32_t w0 = (wi < 0) ? pw : S[wi];
-        const uint32_t w1 = S[wi + 1];
-        return s ? ((w0 << s) | (w1 >> (32u - s))) : w0;
-    };
+    // The first owned byte starts at local bit -(o & 7).  All lanes share the shift s within a word;
+    // lane t's 16 bytes start at word W0 + 4t (W0 = -1 when the first byte begins in the predecessor).
+    const uint32_t s = (32u - (uint32_t)(o & 7u)) & 31u;
+    const int W0 = (o & 7u) ? -1 : 0;
 
     uint32_t* out_words = nullptr;
     uint8_t* out_bytes = nullptr;
-    uint64_t pos = 0, pos0 = 0, wdone = 0;
+    uint64_t wbase = 0;   // global word index of stage[0]
+    uint32_t fill = 0;    // bytes in the stage (uniform)
+    uint32_t head = 0;    // leading bytes of the stage's first word that belong to the previous chunk
     if constexpr (WRITE) {
         out_words = p.words_out + (uint64_t)img * p.out_stride;
         out_bytes = reinterpret_cast<uint8_t*>(out_words);
-        pos0 = pos = q_first + p.ff_off[gid];  // stuffed byte offset of the first owned byte
-        wdone = (pos + 3) >> 2;                // first word this chunk writes whole
+        const uint64_t pos0 = q_first + p.ff_off[gid];  // stuffed byte offset of the first owned byte
+        wbase = pos0 >> 2;
+        head = fill = (uint32_t)(pos0 & 3u);
     }
     const uint64_t cap_bytes = p.cap_words * 4;
     uint32_t ff_total = 0;
-    bool head_done = false;
 
-    for (uint32_t base = 0; base < nbytes; base += 256) {
-        const uint32_t j = base + (uint32_t)lane * 4u;
-        const int nvalid = (j < nbytes) ? (int)min(4u, nbytes - j) : 0;
-        uint32_t v = 0;
-        if (nvalid > 0) v = fetch32(lstart + 8 * (int)j);
-        uint32_t ffm = 0;
+    auto flush = [&](bool final_pad) {
+        // stores the complete words of the stage; keeps the residual bytes for the next step
+        const uint32_t nwords = final_pad ? ((fill + 3u) >> 2) : (fill >> 2);
+        for (uint32_t i = lane; i < nwords; i += 64) {
+            const uint32_t raw = reinterpret_cast<const uint32_t*>(stage)[i];
+            const uint64_t gw = wbase + i;
+            if (i == 0 && head) {  // word shared with the previous chunk: only our bytes
+                for (uint32_t b = head; b < 4; ++b) {
+                    const uint64_t ga = gw * 4 + b;
+                    if (ga < cap_bytes) out_bytes[ga ^ 3] = stage[b];
+                }
+            } else if (gw < p.cap_words) {
+                out_words[gw] = __builtin_bswap32(raw);
+            }
+        }
+        __syncthreads();
+        if (nwords) {
+            const uint32_t rest = final_pad ? 0u : (fill & 3u);
+            if (lane < rest) stage[lane] = stage[nwords * 4 + lane];  // reads and writes are disjoint words
+            wbase += nwords;
+            fill = rest;
+            head = 0;
+        }
+        __syncthreads();
+    };
+
+    for (uint32_t base = 0; base < nbytes; base += 1024) {
+        const uint32_t j = base + (uint32_t)lane * 16u;
+        const int nvalid = (j < nbytes) ? (int)min(16u, nbytes - j) : 0;
+        uint32_t v[4] = {0, 0, 0, 0};
+        if (nvalid > 0) {
+            const int wi = W0 + (int)(j >> 2);
+            Words4 q;
+            if (wi >= 0) {
+                q = *reinterpret_cast<const Words4*>(S + wi);
+            } else {  // only lane 0 of the first step
+                q.w[0] = pw; q.w[1] = S[0]; q.w[2] = S[1]; q.w[3] = S[2];
+            }
+            const uint32_t w4 = S[wi + 4];
+            if (s == 0) {
+                v[0] = q.w[0]; v[1] = q.w[1]; v[2] = q.w[2]; v[3] = q.w[3];
+            } else {
+                v[0] = __builtin_amdgcn_alignbit(q.w[0], q.w[1], 32u - s);
+                v[1] = __builtin_amdgcn_alignbit(q.w[1], q.w[2], 32u - s);
+                v[2] = __builtin_amdgcn_alignbit(q.w[2], q.w[3], 32u - s);
+                v[3] = __builtin_amdgcn_alignbit(q.w[3], w4, 32u - s);
+            }
+        }
+        uint32_t m[4];
+        uint32_t cnt = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (i < nvalid && ((v >> (24 - 8 * i)) & 0xFFu) == 0xFFu) ffm |= 1u << i;
-        const uint32_t cnt = __popc(ffm);
+        for (int i = 0; i < 4; ++i) {
+            const int nb = nvalid - 4 * i;  // valid bytes of word i
+            const uint32_t keep = nb >= 4 ? 0xFFFFFFFFu : nb <= 0 ? 0u : ~(0xFFFFFFFFu >> (8 * nb));
+            m[i] = ff_mask(v[i]) & keep;
+            cnt += __popc(m[i]);
+        }
         if constexpr (!WRITE) {
             ff_total += cnt;
         } else {
             uint32_t it_ff;
             const uint32_t pre = wave_excl_scan_u32(cnt, lane, &it_ff);
-            uint64_t a = pos + j - base + pre;  // stuffed offset of this lane's first byte
+            uint32_t a = fill + (j - base) + pre;  // stage offset of this lane's first byte
+            if (nvalid == 16 && cnt == 0) {
+                uint32_t t[4] = {__builtin_bswap32(v[0]), __builtin_bswap32(v[1]), __builtin_bswap32(v[2]),
+                                 __builtin_bswap32(v[3])};
+                __builtin_memcpy(&stage[a], t, 16);  // byte-aligned 16-byte store
+            } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (i < nvalid) {
-                    ring[((uint32_t)a & 1023u) ^ 3u] = (uint8_t)(v >> (24 - 8 * i));
-                    ++a;
-                    if (ffm & (1u << i)) {
-                        ring[((uint32_t)a & 1023u) ^ 3u] = 0;
-                        ++a;
+                for (int i = 0; i < 4; ++i) {
+                    const int nb = nvalid - 4 * i;
+                    if (nb >= 4 && m[i] == 0) {
+                        const uint32_t t = __builtin_bswap32(v[i]);
+                        __builtin_memcpy(&stage[a], &t, 4);
+                        a += 4;
+                    } else {
+                        for (int b = 0; b < 4 && b < nb; ++b) {
+                            stage[a++] = (uint8_t)(v[i] >> (24 - 8 * b));
+                            if (m[i] & (0x80000000u >> (8 * b))) stage[a++] = 0;
+                        }
                     }
                 }
             }
-            const uint32_t it_bytes = min(256u, nbytes - base) + it_ff;
-            pos += it_bytes;
+            fill += min(1024u, nbytes - base) + it_ff;
             __syncthreads();
-            if (!head_done) {  // bytes before the first whole word: stored one by one
-                const uint64_t hend = min(wdone * 4, pos);
-                const uint64_t ha = pos0 + lane;
-                if (ha < hend && ha < cap_bytes) out_bytes[ha ^ 3] = ring[((uint32_t)ha & 1023u) ^ 3u];
-                head_done = true;
-            }
-            const uint64_t wend = pos >> 2;  // words complete so far
-            for (uint64_t w = wdone + lane; w < wend; w += 64)
-                if (w < p.cap_words) out_words[w] = ring_w[(uint32_t)w & 255u];
-            if (wend > wdone) wdone = wend;
-            __syncthreads();
+            flush(false);
         }
     }
 
@@ -624,31 +679,32 @@ __global__ __launch_bounds__(64) void k_stuff(StuffParams p) {
         const bool last = (c == p.cpi - 1);
         if (!last) {
             // bytes after the last whole word belong to a word shared with the next chunk
-            const uint64_t ta = wdone * 4 + lane;
-            if (ta >= pos0 && ta < pos && ta < cap_bytes) out_bytes[ta ^ 3] = ring[((uint32_t)ta & 1023u) ^ 3u];
+            if ((uint32_t)lane >= head && (uint32_t)lane < fill) {
+                const uint64_t ga = wbase * 4 + lane;
+                if (ga < cap_bytes) out_bytes[ga ^ 3] = stage[lane];
+            }
         } else {
             // end of file: the incomplete last byte is never stuffed; the residual bits are presented
             // left-aligned in one more word with their count (ff_checker.sv:289-360, functional)
             const uint64_t total_bits = o + n;
             const uint32_t rem = (uint32_t)(total_bits & 7u);
-            const uint64_t stuffed_bytes = pos;
-            uint64_t endpos = pos;
+            const uint64_t stuffed_bytes = wbase * 4 + fill;
             if (lane == 0) {
+                uint32_t f = fill;
                 if (rem) {
-                    const uint32_t vb = fetch32((int)(n - rem)) >> 24;
-                    ring[((uint32_t)endpos & 1023u) ^ 3u] = (uint8_t)(vb & (0xFFu << (8u - rem)));
-                    ++endpos;
+                    // the last rem bits of the chunk stream, left-aligned in a byte
+                    const uint32_t l = n - rem, wi = l >> 5, sh = l & 31u;
+                    const uint32_t w32 = sh ? __builtin_amdgcn_alignbit(S[wi], S[wi + 1], 32u - sh) : S[wi];
+                    const uint32_t vb = w32 >> 24;
+                    stage[f++] = (uint8_t)(vb & (0xFFu << (8u - rem)));
                 }
-                while (endpos & 3u) {
-                    ring[((uint32_t)endpos & 1023u) ^ 3u] = 0;
-                    ++endpos;
-                }
+                while (f & 3u) stage[f++] = 0;
             }
-            endpos = __shfl(endpos, 0);
+            fill = (fill + (rem ? 1u : 0u) + 3u) & ~3u;
             __syncthreads();
-            const uint64_t wend = endpos >> 2;
-            for (uint64_t w = wdone + lane; w < wend; w += 64)
-                if (w < p.cap_words) out_words[w] = ring_w[(uint32_t)w & 255u];
+            const uint32_t tail_idx = (uint32_t)(((stuffed_bytes * 8 + rem) >> 5) - wbase);  // word holding the residual
+            const uint32_t tail_raw = (tail_idx * 4 < fill) ? reinterpret_cast<const uint32_t*>(stage)[tail_idx] : 0u;
+            flush(true);
             if (lane == 0) {
                 const uint64_t sbits = stuffed_bytes * 8 + rem;
                 jpegenc_result r;
@@ -657,7 +713,7 @@ __global__ __launch_bounds__(64) void k_stuff(StuffParams p) {
                 r.total_bytes_stuffed = stuffed_bytes;
                 r.tail_bits = (uint8_t)(sbits & 31u);
                 r.eof_partial_ready = r.tail_bits ? 1 : 0;
-                r.tail_word = r.tail_bits ? ring_w[(uint32_t)(r.n_full_words) & 255u] : 0u;
+                r.tail_word = r.tail_bits ? __builtin_bswap32(tail_raw) : 0u;
                 const uint64_t need = r.n_full_words + (r.tail_bits ? 1 : 0);
                 r.status = (need > p.cap_words) ? (int16_t)JPEGENC_E_TOO_SMALL : (int16_t)JPEGENC_OK;
                 p.results[img] = r;
