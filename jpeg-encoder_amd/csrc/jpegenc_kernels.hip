@@ -129,23 +129,31 @@ __device__ __forceinline__ void dct_cols(int (&x)[64]) {
 // region.  `cur` keeps the pending bits right-aligned; bits above `n` are stale and shift out.
 // ------------------------------------------------------------------------------------------------
 struct BitWriter {
-    uint32_t cur;   // pending bits (low n bits valid)
-    uint32_t n;     // 0..31
-    uint32_t wp;    // next LDS word index
-    uint32_t wlim;  // first LDS word index this lane may not fill; doubles as its dump slot
+    uint32_t cur;   // pending bits, right-aligned; bits above the pending count are stale and shift out
+    uint32_t T;     // cumulative bit position in LDS (word index * 32 + bits used in that word)
+    uint32_t addr;  // byte address of the word being filled = (T >> 5) * 4
+    uint32_t dump;  // byte address of the lane's dump slot
+    uint32_t wlim;  // GUARD only: first byte address the lane may not store to
 };
 
-// Branch-free: the store always happens; when no word completes (or the region is full) it goes to the
-// lane's dump slot at wlim.  Shift counts are masked because they are out of range exactly when the
-// value is not used.
+// Branch-free append of (bits,len), len <= 26.  The store always happens: when the append completes a
+// word (the word index of T advances) it goes to that word, otherwise to the lane's dump slot.  All
+// shift counts are taken modulo 32 by the hardware; they are out of range exactly when the shifted
+// value is not used.  GUARD = false is for the first tier, where every lane owns its region and a lane
+// that overruns it merely forces the chunk onto the next tier (the overrun lands in the neighbour's
+// region or in the padding behind the last one, and everything is recomputed); GUARD = true clamps.
+template <bool GUARD>
 __device__ __forceinline__ void bw_emit(BitWriter& s, uint32_t bits, uint32_t len, uint32_t* priv) {
-    const uint32_t t = s.n + len;  // len <= 26, so t < 64 and a completed word implies n >= 6
-    const uint32_t word = (s.cur << ((32u - s.n) & 31u)) | (bits >> ((t - 32u) & 31u));
-    const uint32_t at = (t >= 32u) ? min(s.wp, s.wlim) : s.wlim;
-    priv[at] = word;
-    s.wp += t >> 5;
+    const uint32_t Tn = s.T + len;
+    const uint32_t word = (s.cur << ((0u - s.T) & 31u)) | (bits >> (Tn & 31u));
+    const uint32_t an = (Tn >> 5) << 2;
+    bool adv = an != s.addr;
+    if constexpr (GUARD) adv = adv && (s.addr < s.wlim);
+    const uint32_t at = adv ? s.addr : s.dump;
+    *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(priv) + at) = word;
+    s.addr = an;
+    s.T = Tn;
     s.cur = (s.cur << len) | bits;
-    s.n = t & 31u;
 }
 
 // Huffman-codes one component block (coefficients in Huffman input order) into the lane's writer.
@@ -159,18 +167,29 @@ __device__ __forceinline__ void bw_emit(BitWriter& s, uint32_t bits, uint32_t le
 // expression, and the restriction to bits [9:0] (resp. [10:0] for DC) only matters for values that
 // 8-bit pixels cannot produce (see build_htab).  The table lookup does the rest: the index carries
 // run, size and the end_of_block flag, and empty entries make a zero coefficient emit nothing.
-__device__ __forceinline__ uint32_t mag_bits(int v) { return 32u - (uint32_t)__clz(__builtin_abs(v)); }
-__device__ __forceinline__ uint32_t amp_bits(int v, uint32_t size) {
-    return __builtin_amdgcn_ubfe((uint32_t)(v + (v >> 31)), 0u, size);
+// t = v for v >= 0, v - 1 for v < 0: its low `size` bits are the amplitude, and the number of leading
+// bits equal to its sign bit is 32 - size (v = -4: t = ...11011, 29 leading ones, size 3).
+__device__ __forceinline__ int amp_src(int v) { return v + (v >> 31); }
+// v_ffbh_i32: number of leading bits equal to the sign bit, -1 when all 32 are (t = 0; t = -1 cannot
+// occur since v = 0 maps to t = 0).
+__device__ __forceinline__ int lead_bits(int t) {
+    int lead;
+    asm("v_ffbh_i32 %0, %1" : "=v"(lead) : "v"(t));
+    return lead;
+}
+__device__ __forceinline__ uint32_t mag_bits(int lead) { return 32u - min((uint32_t)lead, 32u); }
+__device__ __forceinline__ uint32_t amp_bits(int t, uint32_t size) {
+    return __builtin_amdgcn_ubfe((uint32_t)t, 0u, size);
 }
 
+template <bool GUARD>
 __device__ __forceinline__ void encode_block(const int (&blk)[64], int dc_pred, bool cb_eob_quirk,
                                              const uint32_t* htab, uint32_t* priv, BitWriter& bw) {
     {   // DC difference, 12 bit (cr_huff.sv:1317): |d| <= 2047 for 11-bit inputs, no wrap possible
-        const int d = blk[0] - dc_pred;
-        const uint32_t size = mag_bits(d);
+        const int t = amp_src(blk[0] - dc_pred);
+        const uint32_t size = mag_bits(lead_bits(t));
         const uint32_t ent = htab[kHtabDc + size];
-        bw_emit(bw, (ent & 0x7FFFFFFu) | amp_bits(d, size), ent >> 27, priv);
+        bw_emit<GUARD>(bw, (ent & 0x7FFFFFFu) | amp_bits(t, size), ent >> 27, priv);
     }
     // group-of-eight all-zero tests over zig-zag indices 16..63 (cr_huff.sv:190-204)
     int o2 = 0, o3 = 0, o4 = 0, o5 = 0, o6 = 0, o7 = 0;
@@ -196,18 +215,22 @@ __device__ __forceinline__ void encode_block(const int (&blk)[64], int dc_pred, 
 #pragma unroll
     for (int k = 1; k <= 62; ++k) {
         const int v = blk[kZZ[k]];
-        const uint32_t size = mag_bits(v);
+        const int t = amp_src(v);
+        const int lead = lead_bits(t);
+        const uint32_t size = mag_bits(lead);
         // a run of 15 zeros cannot complete before k = 16, so the flag only matters from there on
         const uint32_t eob = (k < 16) ? 0u : (k + 2 < 32) ? eob_a : (k + 2 < 48) ? eob_b : eob_c;
         const uint32_t ent = htab[r4 | size | eob];
-        bw_emit(bw, (ent & 0x7FFFFFFu) | amp_bits(v, size), ent >> 27, priv);
-        r4 = (v != 0) ? 0u : ((r4 + 16u) & 0xF0u);
+        bw_emit<GUARD>(bw, (ent & 0x7FFFFFFu) | amp_bits(t, size), ent >> 27, priv);
+        // zero coefficient (lead == -1): run + 1 modulo 16; otherwise the run restarts
+        r4 = (r4 + 16u) & (uint32_t)(lead >> 31) & 0xF0u;
     }
     {
         const int v = blk[63];
-        const uint32_t size = mag_bits(v);
+        const int t = amp_src(v);
+        const uint32_t size = mag_bits(lead_bits(t));
         const uint32_t ent = htab[(v != 0) ? (r4 | size) : (uint32_t)kHtabEob];
-        bw_emit(bw, (ent & 0x7FFFFFFu) | amp_bits(v, size), ent >> 27, priv);
+        bw_emit<GUARD>(bw, (ent & 0x7FFFFFFu) | amp_bits(t, size), ent >> 27, priv);
     }
 }
 
@@ -297,7 +320,7 @@ __device__ __forceinline__ int halo_dc(int sample, bool luma, int qm0, bool do_q
 // 32 lanes (two regions each, 4096 bits), then with 4 groups of 16 lanes (four regions, 258 words -- more
 // than the 156-word worst case of an MCU).  Odd region strides keep lanes on different LDS banks.
 constexpr int kRegionWords = 65;
-constexpr int kPrivWords = 64 * kRegionWords;  // 4160 words = 16,640 B
+constexpr int kPrivWords = 64 * kRegionWords + 96;  // 4256 words: the regions plus room for the last lane's overrun (156 words)
 
 template <int ALIGN, bool QUANT, bool WRAP>
 __global__ __launch_bounds__(64, 2) void k_encode_chunks(EncodeParams p) {
@@ -348,14 +371,14 @@ __global__ __launch_bounds__(64, 2) void k_encode_chunks(EncodeParams p) {
         const uint32_t cap = stride - 2u;
         const bool active = valid && (lane / lanes_per_group) == g;
         const uint32_t base = (uint32_t)(lane & (lanes_per_group - 1)) * stride;
+        // usable words [base, base+cap), spare word, dump slot at base+stride-1; lanes of other groups
+        // count their bits but only ever store to the dump slot
         BitWriter bw;
         bw.cur = 0;
-        bw.n = 0;
-        // usable words [base, base+cap), dump slot base+cap; lanes of other groups count their bits but
-        // only ever store to the spare last word of the region
-        const uint32_t wp0 = active ? base : base + stride - 1u;
-        bw.wp = wp0;
-        bw.wlim = active ? base + cap : wp0;
+        bw.T = base * 32u;
+        bw.addr = base * 4u;
+        bw.dump = (base + stride - 1u) * 4u;
+        bw.wlim = active ? (base + cap) * 4u : 0u;
 
 #pragma unroll 1
         for (int comp = 0; comp < 3; ++comp) {
@@ -399,13 +422,17 @@ __global__ __launch_bounds__(64, 2) void k_encode_chunks(EncodeParams p) {
             int pred = __shfl_up(x[0], 1);
             const int h = (comp == 0) ? halo[0] : (comp == 1) ? halo[1] : halo[2];
             if (lane == 0) pred = h;
-            encode_block(x, pred, comp == 1 && cb_quirk, htab, priv, bw);
+            if (n_groups == 1)
+                encode_block<false>(x, pred, comp == 1 && cb_quirk, htab, priv, bw);
+            else
+                encode_block<true>(x, pred, comp == 1 && cb_quirk, htab, priv, bw);
         }
-        // flush the residual bits, left-aligned and zero-filled
-        if (active && bw.n != 0 && bw.wp < bw.wlim) priv[bw.wp] = bw.cur << (32u - bw.n);
         // Every lane counts its bits whether or not it may store them, so the first pass already knows
         // which tier the chunk needs.
-        const uint32_t Lall = valid ? ((bw.wp - wp0) * 32u + bw.n) : 0u;
+        const uint32_t Lall = valid ? (bw.T - base * 32u) : 0u;
+        // flush the residual bits, left-aligned and zero-filled
+        if (active && (bw.T & 31u) != 0 && Lall <= cap * 32u)
+            priv[bw.T >> 5] = bw.cur << ((0u - bw.T) & 31u);
         if (n_groups == 1 && __any((int)(Lall > cap * 32u))) {
             n_groups = __any((int)(Lall > (2u * kRegionWords - 2u) * 32u)) ? 4 : 2;
             g = -1;  // restart the chunk on that tier
