@@ -124,6 +124,84 @@ __device__ __forceinline__ void dct_cols(int (&x)[64]) {
              x[7 * 8 + k], DctK<LUMA>::b2, DctK<LUMA>::b2, DctK<LUMA>::sh2);
 }
 
+// ---- packed form of the same transform ------------------------------------------------------------
+// Two 16-bit values per register: v_pk_add/sub_i16 fold two pairs at once and v_dot2_i32_i16 does two
+// multiply-adds per instruction, exactly (16 x 16 -> 32-bit products, 32-bit accumulate; every operand
+// fits 16 bits: |fold| <= 5792, |T| <= 8035).  Same integers as dct8(), 18 instructions instead of 36.
+__device__ __forceinline__ int pk_add(int a, int b) {
+    int r;
+    asm("v_pk_add_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ int pk_sub(int a, int b) {
+    int r;
+    asm("v_pk_sub_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// (a.lo + b.hi, a.hi + b.lo) and (a.lo - b.hi, a.hi - b.lo)
+__device__ __forceinline__ int pk_add_x(int a, int b) {
+    int r;
+    asm("v_pk_add_i16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ int pk_sub_x(int a, int b) {
+    int r;
+    asm("v_pk_sub_i16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// acc + a.lo * c.lo + a.hi * c.hi
+__device__ __forceinline__ int dot2(int a, int c, int acc) {
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(c), "v"(acc));
+    return r;
+}
+__host__ __device__ constexpr int cpair(int lo, int hi) { return (int)(((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16)); }
+__device__ __forceinline__ int pack16(int lo, int hi) {  // low halves of two registers
+    return (int)__builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u);
+}
+
+// Inputs as pairs p01 = (x0,x1), p23 = (x2,x3), p76 = (x7,x6), p54 = (x5,x4); y[k] = (sum + bias) >> sh.
+__device__ __forceinline__ void dct8p(int p01, int p23, int p76, int p54, int bias0, int bias, int sh, int (&y)[8]) {
+    const int s01 = pk_add(p01, p76), s23 = pk_add(p23, p54);  // (s0,s1), (s2,s3)
+    const int d01 = pk_sub(p01, p76), d23 = pk_sub(p23, p54);  // (d0,d1), (d2,d3)
+    const int e = pk_add_x(s01, s23);                           // (s0+s3, s1+s2)
+    const int f = pk_sub_x(s01, s23);                           // (s0-s3, s1-s2)
+    y[0] = dot2(e, cpair(5793, 5793), bias0) >> sh;
+    y[4] = dot2(e, cpair(5793, -5793), bias) >> sh;
+    y[2] = dot2(f, cpair(7568, 3135), bias) >> sh;
+    y[6] = dot2(f, cpair(3135, -7568), bias) >> sh;
+    y[1] = dot2(d23, cpair(4551, 1598), dot2(d01, cpair(8035, 6811), bias)) >> sh;
+    y[3] = dot2(d23, cpair(-8035, -4551), dot2(d01, cpair(6811, -1598), bias)) >> sh;
+    y[5] = dot2(d23, cpair(1598, 6811), dot2(d01, cpair(4551, -8035), bias)) >> sh;
+    y[7] = dot2(d23, cpair(6811, -8035), dot2(d01, cpair(1598, -4551), bias)) >> sh;
+}
+
+// Pass 1 on two consecutive rows of samples (c0: row 2i, c1: row 2i+1, values 0..255) and packing of
+// the results for pass 2: col[k] = (B[lo_row][k], B[hi_row][k]) with lo_row = 2i for the upper half of
+// the block and 2i+1 for the lower half (pass 2 wants the pairs (B0,B1), (B2,B3), (B5,B4), (B7,B6)).
+template <bool LUMA>
+__device__ __forceinline__ void dct_row_pair(const int (&c0)[8], const int (&c1)[8], bool lower_half, int (&col)[8]) {
+    int y0[8], y1[8];
+    dct8p(c0[0] | (c0[1] << 16), c0[2] | (c0[3] << 16), c0[7] | (c0[6] << 16), c0[5] | (c0[4] << 16),
+          DctK<LUMA>::b1 - JPEGENC_DCT_LEVEL_SHIFT, DctK<LUMA>::b1, DctK<LUMA>::sh1, y0);
+    dct8p(c1[0] | (c1[1] << 16), c1[2] | (c1[3] << 16), c1[7] | (c1[6] << 16), c1[5] | (c1[4] << 16),
+          DctK<LUMA>::b1 - JPEGENC_DCT_LEVEL_SHIFT, DctK<LUMA>::b1, DctK<LUMA>::sh1, y1);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) col[k] = lower_half ? pack16(y1[k], y0[k]) : pack16(y0[k], y1[k]);
+}
+
+// Pass 2: column k from its four row pairs -> x[j*8+k], j = vertical frequency.
+template <bool LUMA>
+__device__ __forceinline__ void dct_cols_packed(const int (&pc)[4][8], int (&x)[64]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        int y[8];
+        dct8p(pc[0][k], pc[1][k], pc[3][k], pc[2][k], DctK<LUMA>::b2, DctK<LUMA>::b2, DctK<LUMA>::sh2, y);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j * 8 + k] = y[j];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Per-lane bit writer: appends (bits,len) MSB-first; full 32-bit words go to the lane's private LDS
 // region.  `cur` keeps the pending bits right-aligned; bits above `n` are stale and shift out.
@@ -392,26 +470,36 @@ __global__ __launch_bounds__(64, 2) void k_encode_chunks(EncodeParams p) {
             // the optimiser from folding them back into one body with run-time shift counts.  Each row
             // is converted and transformed before the next one is touched, so the raw pixels die early.
             if (comp == 0) {
+                int pc[4][8];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
+                for (int i = 0; i < 4; ++i) {
+                    int c0[8], c1[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        x[r * 8 + q] = colour<0>(raw_byte(raw, r, 3 * q), raw_byte(raw, r, 3 * q + 1),
-                                                 raw_byte(raw, r, 3 * q + 2), cc.k0, cc.cr, cc.cg, cc.cb);
-                    dct_row<true>(x, r);
+                    for (int q = 0; q < 8; ++q) {
+                        c0[q] = colour<0>(raw_byte(raw, 2 * i, 3 * q), raw_byte(raw, 2 * i, 3 * q + 1),
+                                          raw_byte(raw, 2 * i, 3 * q + 2), cc.k0, cc.cr, cc.cg, cc.cb);
+                        c1[q] = colour<0>(raw_byte(raw, 2 * i + 1, 3 * q), raw_byte(raw, 2 * i + 1, 3 * q + 1),
+                                          raw_byte(raw, 2 * i + 1, 3 * q + 2), cc.k0, cc.cr, cc.cg, cc.cb);
+                    }
+                    dct_row_pair<true>(c0, c1, i >= 2, pc[i]);
                 }
-                dct_cols<true>(x);
+                dct_cols_packed<true>(pc, x);
                 asm volatile("; luma dct done" ::: "memory");
             } else {
+                int pc[4][8];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
+                for (int i = 0; i < 4; ++i) {
+                    int c0[8], c1[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        x[r * 8 + q] = colour<WRAP ? 1 : 2>(raw_byte(raw, r, 3 * q), raw_byte(raw, r, 3 * q + 1),
-                                                            raw_byte(raw, r, 3 * q + 2), cc.k0, cc.cr, cc.cg, cc.cb);
-                    dct_row<false>(x, r);
+                    for (int q = 0; q < 8; ++q) {
+                        c0[q] = colour<WRAP ? 1 : 2>(raw_byte(raw, 2 * i, 3 * q), raw_byte(raw, 2 * i, 3 * q + 1),
+                                                     raw_byte(raw, 2 * i, 3 * q + 2), cc.k0, cc.cr, cc.cg, cc.cb);
+                        c1[q] = colour<WRAP ? 1 : 2>(raw_byte(raw, 2 * i + 1, 3 * q), raw_byte(raw, 2 * i + 1, 3 * q + 1),
+                                                     raw_byte(raw, 2 * i + 1, 3 * q + 2), cc.k0, cc.cr, cc.cg, cc.cb);
+                    }
+                    dct_row_pair<false>(c0, c1, i >= 2, pc[i]);
                 }
-                dct_cols<false>(x);
+                dct_cols_packed<false>(pc, x);
                 asm volatile("; chroma dct done" ::: "memory");
             }
             if constexpr (QUANT) {
