@@ -173,7 +173,8 @@ def main():
             tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tfile):
                 try:
-                    traffic = json.load(open(tfile)).get("k_encode_chunks_hbm_bytes_per_launch")
+                    per_frame = json.load(open(tfile)).get("k_encode_chunks_hbm_bytes_per_frame")
+                    traffic = round(per_frame * nf / launches_per_step) if per_frame else None
                 except Exception:
                     traffic = None
             line["roofline"] = {"bound": "hbm", "kernel": "k_encode_chunks", "achieved": round(achieved, 1),
