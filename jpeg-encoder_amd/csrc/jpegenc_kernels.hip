@@ -393,15 +393,19 @@ __device__ __forceinline__ int halo_dc(int sample, bool luma, int qm0, bool do_q
 // ------------------------------------------------------------------------------------------------
 // k_encode_chunks
 // ------------------------------------------------------------------------------------------------
-// LDS budget: 64 regions of 65 words.  Tier 1 gives every lane one region (63 usable words = 2016 bits
-// per MCU, enough for photographic content); if any lane overflows, the chunk is redone with 2 groups of
-// 32 lanes (two regions each, 4096 bits), then with 4 groups of 16 lanes (four regions, 258 words -- more
+// LDS budget: 64 regions of 41 words, sized so that twelve workgroups (three waves per SIMD) fit the
+// 160 KB of a CU.  Tier 1 gives every lane one region (39 usable words = 1248 bits per MCU, 2.4 bytes per
+// pixel: enough for photographic content); if any lane overflows, the chunk is redone with 2 groups of
+// 32 lanes (two regions each, 80 words), then with 4 groups of 16 lanes (four regions, 162 words -- more
 // than the 156-word worst case of an MCU).  Odd region strides keep lanes on different LDS banks.
-constexpr int kRegionWords = 65;
-constexpr int kPrivWords = 64 * kRegionWords + 96;  // 4256 words: the regions plus room for the last lane's overrun (156 words)
+constexpr int kRegionWords = 41;
+// The regions plus room for the unguarded tier-1 overrun of the last lane (156 words from its base).
+constexpr int kPrivWords = 64 * kRegionWords + 120;
+static_assert(63 * kRegionWords + kMaxMcuWords <= kPrivWords, "tier-1 overrun of the last lane");
+static_assert(4 * kRegionWords - 2 >= kMaxMcuWords, "tier 3 must hold the worst-case MCU");
 
 template <int ALIGN, bool QUANT, bool WRAP>
-__global__ __launch_bounds__(64, 2) void k_encode_chunks(EncodeParams p) {
+__global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
     __shared__ uint32_t priv[kPrivWords];
     __shared__ uint32_t htab[kHtabEntries];
     const int lane = threadIdx.x;
