@@ -43,6 +43,20 @@ __device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, int lane, uin
     return x - v;
 }
 
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d));
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+// Orders one wave's LDS traffic for a single-wave workgroup: the compiler may not move LDS accesses
+// across it, and the hardware serves a wave's LDS instructions in order.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int l) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, l);
 }
@@ -399,6 +413,8 @@ __device__ __forceinline__ int halo_dc(int sample, bool luma, int qm0, bool do_q
 // 32 lanes (two regions each, 80 words), then with 4 groups of 16 lanes (four regions, 162 words -- more
 // than the 156-word worst case of an MCU).  Odd region strides keep lanes on different LDS banks.
 constexpr int kRegionWords = 41;
+constexpr int kOwnWords = kRegionWords - 1;  // first tier: 39 usable words and one zero word behind them
+static_assert(kOwnWords % 8 == 0, "the in-register concatenation works in blocks of 8 words");
 // The regions plus room for the unguarded tier-1 overrun of the last lane (156 words from its base).
 constexpr int kPrivWords = 64 * kRegionWords + 120;
 static_assert(63 * kRegionWords + kMaxMcuWords <= kPrivWords, "tier-1 overrun of the last lane");
@@ -523,8 +539,10 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
         // which tier the chunk needs.
         const uint32_t Lall = valid ? (bw.T - base * 32u) : 0u;
         // flush the residual bits, left-aligned and zero-filled
-        if (active && (bw.T & 31u) != 0 && Lall <= cap * 32u)
-            priv[bw.T >> 5] = bw.cur << ((0u - bw.T) & 31u);
+        if (active && Lall <= cap * 32u) {
+            if ((bw.T & 31u) != 0) priv[bw.T >> 5] = bw.cur << ((0u - bw.T) & 31u);
+            priv[(bw.T + 31u) >> 5] = 0u;  // one zero word behind the string (at most the spare word)
+        }
         if (n_groups == 1 && __any((int)(Lall > cap * 32u))) {
             n_groups = __any((int)(Lall > (2u * kRegionWords - 2u) * 32u)) ? 4 : 2;
             g = -1;  // restart the chunk on that tier
@@ -541,9 +559,42 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
         // string never moves to a higher address and all reads of a step precede its writes.
         uint32_t gtotal;
         const uint32_t off = wave_excl_scan_u32(L, lane, &gtotal);
+        if (n_groups == 1) {
+            // First tier, every lane at once: each lane takes its whole string (at most kOwnWords words,
+            // the last one zero) into registers, the destination range is cleared, and every lane ORs
+            // its words, shifted to its bit offset, into place.  Words shared by neighbouring strings
+            // get their parts from several lanes, hence the OR.  In place is safe because all reads
+            // come first: the LDS serves one wave's instructions in order.
+            const uint32_t s = off & 31u, j0 = off >> 5;
+            const uint32_t nd = L ? ((s + L + 31u) >> 5) : 0u;  // destination words touched
+            const uint32_t nmax = wave_max_u32(nd);             // uniform, <= kOwnWords
+            uint32_t own[kOwnWords];
+#pragma unroll
+            for (int t0 = 0; t0 < kOwnWords; t0 += 8) {
+                if ((uint32_t)t0 < nmax) {
+#pragma unroll
+                    for (int t = t0; t < t0 + 8; ++t) own[t] = priv[base + t];
+                }
+            }
+            wave_sync();
+            for (uint32_t i = lane; i < ((gtotal + 31u) >> 5); i += 64) priv[i] = 0u;
+            wave_sync();
+#pragma unroll
+            for (int t0 = 0; t0 < kOwnWords; t0 += 8) {
+                if ((uint32_t)t0 < nmax) {
+#pragma unroll
+                    for (int t = t0; t < t0 + 8; ++t) {
+                        const uint32_t w = __builtin_amdgcn_alignbit(t ? own[t - 1] : 0u, own[t], s);
+                        if ((uint32_t)t < nd)
+                            __hip_atomic_fetch_or(&priv[j0 + t], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+            wave_sync();
+        }
         const int first = g * lanes_per_group;
         uint32_t tailw = 0;
-        for (int m = 0; m < lanes_per_group; ++m) {
+        for (int m = 0; n_groups != 1 && m < lanes_per_group; ++m) {
             const int M = first + m;
             const uint32_t LM = readlane_u32(L, M);
             if (LM == 0) continue;  // uniform
