@@ -217,35 +217,33 @@ __device__ __forceinline__ void dct_cols_packed(const int (&pc)[4][8], int (&x)[
 }
 
 // ------------------------------------------------------------------------------------------------
-// Per-lane bit writer: appends (bits,len) MSB-first; full 32-bit words go to the lane's private LDS
-// region.  `cur` keeps the pending bits right-aligned; bits above `n` are stale and shift out.
+// Per-lane bit writer: appends (bits,len) MSB-first into the lane's private LDS region.
+// `win` holds the last 64 bits of the string.  Every append stores the most recently completed 32-bit
+// word again (the same value until the next word completes), so there is no "did a word complete"
+// decision: the word ending at the last word boundary is win >> (T & 31), and it belongs at word index
+// (T >> 5) - 1 of the string.  T is kept one word low instead (string word w is priv word w + 1 of the
+// region), so the store goes to priv word T >> 5; before the first word completes it lands in the
+// region's word 0, which is never read.
 // ------------------------------------------------------------------------------------------------
 struct BitWriter {
-    uint32_t cur;   // pending bits, right-aligned; bits above the pending count are stale and shift out
-    uint32_t T;     // cumulative bit position in LDS (word index * 32 + bits used in that word)
-    uint32_t addr;  // byte address of the word being filled = (T >> 5) * 4
-    uint32_t dump;  // byte address of the lane's dump slot
-    uint32_t wlim;  // GUARD only: first byte address the lane may not store to
+    uint64_t win;   // the last 64 bits appended (older bits shift out)
+    uint32_t T;     // bit position: priv word index of the last completed word * 32 + pending bits
+    uint32_t dump;  // GUARD only: byte address of the region's word 0
+    uint32_t wlim;  // GUARD only: first byte address the lane may not store to (0: store nothing)
 };
 
-// Branch-free append of (bits,len), len <= 26.  The store always happens: when the append completes a
-// word (the word index of T advances) it goes to that word, otherwise to the lane's dump slot.  All
-// shift counts are taken modulo 32 by the hardware; they are out of range exactly when the shifted
-// value is not used.  GUARD = false is for the first tier, where every lane owns its region and a lane
-// that overruns it merely forces the chunk onto the next tier (the overrun lands in the neighbour's
-// region or in the padding behind the last one, and everything is recomputed); GUARD = true clamps.
+// Branch-free append of (bits,len), len <= 26 (one append completes at most one word).  GUARD = false
+// is for the first tier, where every lane owns its region and a lane that overruns it merely forces the
+// chunk onto the next tier (the overrun lands in the neighbour's region or in the padding behind the
+// last one, and everything is recomputed); GUARD = true diverts such stores to the region's word 0.
 template <bool GUARD>
 __device__ __forceinline__ void bw_emit(BitWriter& s, uint32_t bits, uint32_t len, uint32_t* priv) {
-    const uint32_t Tn = s.T + len;
-    const uint32_t word = (s.cur << ((0u - s.T) & 31u)) | (bits >> (Tn & 31u));
-    const uint32_t an = (Tn >> 5) << 2;
-    bool adv = an != s.addr;
-    if constexpr (GUARD) adv = adv && (s.addr < s.wlim);
-    const uint32_t at = adv ? s.addr : s.dump;
+    s.T += len;
+    s.win = (s.win << len) | bits;
+    const uint32_t word = __builtin_amdgcn_alignbit((uint32_t)(s.win >> 32), (uint32_t)s.win, s.T);
+    uint32_t at = (s.T >> 3) & ~3u;
+    if constexpr (GUARD) at = (at < s.wlim) ? at : s.dump;
     *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(priv) + at) = word;
-    s.addr = an;
-    s.T = Tn;
-    s.cur = (s.cur << len) | bits;
 }
 
 // Huffman-codes one component block (coefficients in Huffman input order) into the lane's writer.
@@ -469,14 +467,14 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
         const uint32_t cap = stride - 2u;
         const bool active = valid && (lane / lanes_per_group) == g;
         const uint32_t base = (uint32_t)(lane & (lanes_per_group - 1)) * stride;
-        // usable words [base, base+cap), spare word, dump slot at base+stride-1; lanes of other groups
-        // count their bits but only ever store to the dump slot
+        // region: word 0 takes the stores of the bit writer that are not meant to land, words [1, 1+cap)
+        // the string, one more word the zero behind a full string; lanes of other groups count their
+        // bits but store nothing
         BitWriter bw;
-        bw.cur = 0;
+        bw.win = 0;
         bw.T = base * 32u;
-        bw.addr = base * 4u;
-        bw.dump = (base + stride - 1u) * 4u;
-        bw.wlim = active ? (base + cap) * 4u : 0u;
+        bw.dump = base * 4u;
+        bw.wlim = active ? (base + 1u + cap) * 4u : 0u;
 
 #pragma unroll 1
         for (int comp = 0; comp < 3; ++comp) {
@@ -540,8 +538,8 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
         const uint32_t Lall = valid ? (bw.T - base * 32u) : 0u;
         // flush the residual bits, left-aligned and zero-filled
         if (active && Lall <= cap * 32u) {
-            if ((bw.T & 31u) != 0) priv[bw.T >> 5] = bw.cur << ((0u - bw.T) & 31u);
-            priv[(bw.T + 31u) >> 5] = 0u;  // one zero word behind the string (at most the spare word)
+            if ((bw.T & 31u) != 0) priv[(bw.T >> 5) + 1u] = (uint32_t)bw.win << ((0u - bw.T) & 31u);
+            priv[((bw.T + 31u) >> 5) + 1u] = 0u;  // one zero word behind the string
         }
         if (n_groups == 1 && __any((int)(Lall > cap * 32u))) {
             n_groups = __any((int)(Lall > (2u * kRegionWords - 2u) * 32u)) ? 4 : 2;
@@ -573,7 +571,7 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
             for (int t0 = 0; t0 < kOwnWords; t0 += 8) {
                 if ((uint32_t)t0 < nmax) {
 #pragma unroll
-                    for (int t = t0; t < t0 + 8; ++t) own[t] = priv[base + t];
+                    for (int t = t0; t < t0 + 8; ++t) own[t] = priv[base + 1 + t];
                 }
             }
             wave_sync();
@@ -599,7 +597,7 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
             const uint32_t LM = readlane_u32(L, M);
             if (LM == 0) continue;  // uniform
             const uint32_t oM = readlane_u32(off, M);
-            const uint32_t bM = (uint32_t)m * stride;
+            const uint32_t bM = (uint32_t)m * stride + 1u;
             const uint32_t s = oM & 31u, d0 = oM >> 5;
             const uint32_t nw = (LM + 31u) >> 5;      // source words
             const uint32_t nd = (s + LM + 31u) >> 5;  // destination words touched
