@@ -33,6 +33,7 @@ def parse_args():
     ap.add_argument("--content", choices=["natural", "noise"], default="natural")
     ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the batch timed on the CPU oracle")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--ws-mb", type=int, default=0, help="workspace limit in MiB (0: library default)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     return ap.parse_args()
@@ -116,6 +117,9 @@ def main():
     torch.cuda.synchronize()
 
     enc = pkg.JpegTop(device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
+
+    if args.ws_mb:
+        enc.set_workspace_limit(args.ws_mb << 20)
 
     def step():
         enc.encode_batch_device(frames.data_ptr(), nf, w, h, w * 3, h * w * 3, words.data_ptr(), cap_words,

@@ -83,7 +83,7 @@ struct jpegenc_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    size_t ws_limit = size_t(4) << 30;
+    size_t ws_limit = size_t(32) << 30;
     bool quant = false;
     uint32_t flags = 0;
 

@@ -458,6 +458,7 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
     uint32_t* slot = p.slots + (uint64_t)gid * kSlotWords;
     uint32_t chunk_total = 0;  // bits written to the slot so far
     uint32_t carry = 0;        // partial last word of the slot (left-aligned), when chunk_total % 32 != 0
+    uint32_t tail8 = 0;        // last 8 bits of the stream so far (uniform)
 
     // Tier loop: n_groups = 1, 2 or 4 groups of 64/n_groups lanes coding at once (see kRegionWords).
     int n_groups = 1;
@@ -640,6 +641,10 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
                 slot[d0 + t] = w;
             }
             const uint32_t nt = chunk_total + gtotal;
+            {   // the last 8 bits of the stream so far (a non-empty group has at least 18 bits)
+                const uint32_t l = gtotal - 8u, wi = l >> 5, sh = l & 31u;
+                tail8 = (sh ? ((priv[wi] << sh) | (priv[wi + 1] >> (32u - sh))) : priv[wi]) >> 24;
+            }
             if (nt & 31u) {  // keep the partial last word for the next group (uniform)
                 const uint32_t t = nd - 1;
                 const uint32_t lo = (t < nw) ? priv[t] : 0u;
@@ -654,12 +659,15 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
         }
         __syncthreads();  // LDS free for the next group
     }
-    if (lane == 0) p.chunk_bits[gid] = chunk_total;
+    // bit count (at most 64 * 4980 < 2^24) and, for the successor's first byte, the stream's last 8 bits
+    if (lane == 0) p.chunk_bits[gid] = chunk_total | (tail8 << 24);
 }
 
 // ------------------------------------------------------------------------------------------------
 // k_scan: exclusive prefix per image, one 256-thread workgroup per image.
 // ------------------------------------------------------------------------------------------------
+constexpr uint32_t kCountMask = 0xFFFFFFu;  // counts live in the low 24 bits of their words
+
 __global__ __launch_bounds__(256) void k_scan(ScanParams p) {
     __shared__ uint64_t part[256];
     const uint32_t img = blockIdx.x;
@@ -668,7 +676,7 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams p) {
     const uint32_t per = (p.cpi + 255u) / 256u;
     const uint32_t lo = min(threadIdx.x * per, p.cpi), hi = min(lo + per, p.cpi);
     uint64_t sum = 0;
-    for (uint32_t i = lo; i < hi; ++i) sum += in[i];
+    for (uint32_t i = lo; i < hi; ++i) sum += in[i] & kCountMask;
     part[threadIdx.x] = sum;
     __syncthreads();
     for (int d = 1; d < 256; d <<= 1) {
@@ -680,7 +688,7 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams p) {
     uint64_t run = part[threadIdx.x] - sum;
     for (uint32_t i = lo; i < hi; ++i) {
         out[i] = run;
-        run += in[i];
+        run += in[i] & kCountMask;
     }
 }
 
@@ -707,26 +715,24 @@ __device__ __forceinline__ uint32_t ff_mask(uint32_t v) {
 
 constexpr int kStageBytes = 2048 + 64;  // one step: <= 1024 bytes, doubled by stuffing, + residual
 
+constexpr int kStuffWaves = 4;
+constexpr int kStuffDepth = 5;  // steps whose loads are in flight together
+
 template <bool WRITE>
-__global__ __launch_bounds__(64) void k_stuff(StuffParams p) {
-    __shared__ __attribute__((aligned(16))) uint8_t stage[WRITE ? kStageBytes : 16];
-    const int lane = threadIdx.x;
-    const uint32_t gid = blockIdx.x;
+__global__ __launch_bounds__(64 * kStuffWaves) void k_stuff(StuffParams p, uint32_t n_chunks) {
+    // kStuffWaves independent waves per workgroup, one chunk each: nothing is shared between them
+    __shared__ __attribute__((aligned(16))) uint8_t stage_all[kStuffWaves][WRITE ? kStageBytes : 16];
+    uint8_t* const stage = stage_all[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    const uint32_t gid = blockIdx.x * kStuffWaves + (threadIdx.x >> 6);
+    if (gid >= n_chunks) return;
     const uint32_t img = gid / p.cpi;
     const uint32_t c = gid - img * p.cpi;
-    const uint32_t n = p.chunk_bits[gid];
+    const uint32_t n = p.chunk_bits[gid] & kCountMask;
     const uint64_t o = p.bit_off[gid];
     const uint32_t* S = p.slots + (uint64_t)gid * kSlotWords;
-
-    // last 32 bits of the predecessor's stream (it has >= 1152 bits): stands in for word -1
-    uint32_t pw = 0;
-    if (c > 0 && (o & 7u)) {
-        const uint32_t np = p.chunk_bits[gid - 1];
-        const uint32_t* Sp = S - kSlotWords;
-        const uint32_t l = np - 32u, wi = l >> 5, s = l & 31u;
-        const uint32_t w0 = Sp[wi];
-        pw = s ? ((w0 << s) | (Sp[wi + 1] >> (32u - s))) : w0;
-    }
+    // the predecessor's last 8 bits stand in for word -1: only the low o & 7 bits of it are used
+    const uint32_t pw = (c > 0) ? (p.chunk_bits[gid - 1] >> 24) : 0u;
     const uint64_t q_first = o >> 3;
     const uint64_t q_end = (o + n) >> 3;
     const uint32_t nbytes = (uint32_t)(q_end - q_first);
@@ -765,7 +771,7 @@ __global__ __launch_bounds__(64) void k_stuff(StuffParams p) {
                 out_words[gw] = __builtin_bswap32(raw);
             }
         }
-        __syncthreads();
+        wave_sync();
         if (nwords) {
             const uint32_t rest = final_pad ? 0u : (fill & 3u);
             if (lane < rest) stage[lane] = stage[nwords * 4 + lane];  // reads and writes are disjoint words
@@ -773,22 +779,40 @@ __global__ __launch_bounds__(64) void k_stuff(StuffParams p) {
             fill = rest;
             head = 0;
         }
-        __syncthreads();
+        wave_sync();
     };
 
+    // One step's raw words of this lane: 16 bytes from word W0 + (base + 16 * lane) / 4 and the word after
+    // them.  The next step's words are requested before the current step is worked on.
+    struct Raw {
+        Words4 q;
+        uint32_t w4;
+    };
+    auto fetch = [&](uint32_t base) {
+        Raw r;
+        r.q.w[0] = r.q.w[1] = r.q.w[2] = r.q.w[3] = r.w4 = 0;
+        const uint32_t j = base + (uint32_t)lane * 16u;
+        if (j < nbytes) {
+            const int wi = W0 + (int)(j >> 2);
+            if (wi >= 0) {
+                r.q = *reinterpret_cast<const Words4*>(S + wi);
+            } else {  // only lane 0 of the first step
+                r.q.w[0] = pw; r.q.w[1] = S[0]; r.q.w[2] = S[1]; r.q.w[3] = S[2];
+            }
+            r.w4 = S[wi + 4];
+        }
+        return r;
+    };
+    Raw nxt = fetch(0);
     for (uint32_t base = 0; base < nbytes; base += 1024) {
         const uint32_t j = base + (uint32_t)lane * 16u;
         const int nvalid = (j < nbytes) ? (int)min(16u, nbytes - j) : 0;
+        const Raw cur = nxt;
+        if (base + 1024 < nbytes) nxt = fetch(base + 1024);
         uint32_t v[4] = {0, 0, 0, 0};
         if (nvalid > 0) {
-            const int wi = W0 + (int)(j >> 2);
-            Words4 q;
-            if (wi >= 0) {
-                q = *reinterpret_cast<const Words4*>(S + wi);
-            } else {  // only lane 0 of the first step
-                q.w[0] = pw; q.w[1] = S[0]; q.w[2] = S[1]; q.w[3] = S[2];
-            }
-            const uint32_t w4 = S[wi + 4];
+            const Words4& q = cur.q;
+            const uint32_t w4 = cur.w4;
             if (s == 0) {
                 v[0] = q.w[0]; v[1] = q.w[1]; v[2] = q.w[2]; v[3] = q.w[3];
             } else {
@@ -834,7 +858,7 @@ __global__ __launch_bounds__(64) void k_stuff(StuffParams p) {
                 }
             }
             fill += min(1024u, nbytes - base) + it_ff;
-            __syncthreads();
+            wave_sync();
             flush(false);
         }
     }
@@ -869,7 +893,7 @@ __global__ __launch_bounds__(64) void k_stuff(StuffParams p) {
                 while (f & 3u) stage[f++] = 0;
             }
             fill = (fill + (rem ? 1u : 0u) + 3u) & ~3u;
-            __syncthreads();
+            wave_sync();
             const uint32_t tail_idx = (uint32_t)(((stuffed_bytes * 8 + rem) >> 5) - wbase);  // word holding the residual
             const uint32_t tail_raw = (tail_idx * 4 < fill) ? reinterpret_cast<const uint32_t*>(stage)[tail_idx] : 0u;
             flush(true);
@@ -888,6 +912,87 @@ __global__ __launch_bounds__(64) void k_stuff(StuffParams p) {
             }
         }
     }
+}
+
+// bit 7 of every byte of the result is set iff that byte of v is 0xFF: the low seven bits plus one carry
+// into bit 7 exactly when they are all ones, and never beyond the byte
+__device__ __forceinline__ uint32_t ff_flags(uint32_t v) {
+    const uint32_t t = (v & 0x7F7F7F7Fu) + 0x01010101u;
+    return t & v & 0x80808080u;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_stuff_count: number of 0xFF bytes each chunk owns (see k_stuff for the ownership rule).  One wave
+// per chunk, 16 stream bytes per lane and step.  The byte that begins in the predecessor is taken on
+// its own; the bytes after it start A = (8 - o % 8) % 8 bits into the chunk's stream, so lane t's four
+// shifted words come from one aligned 16-byte load at word 256 * step + 4 * t and the word behind it.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_count(StuffParams p, uint32_t n_chunks) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t gid = blockIdx.x * kStuffWaves + (threadIdx.x >> 6);
+    if (gid >= n_chunks) return;
+    const uint32_t* S = p.slots + (uint64_t)gid * kSlotWords;
+    // The first kStuffDepth steps' words are requested before the chunk's bit count and offset are known
+    // (their addresses depend on neither), so a photographic chunk costs one memory round trip, not one
+    // for the counts and one per step.  Words behind the chunk's end are read (the slot is always large
+    // enough) and ignored.
+    uint4 w[kStuffDepth];
+    uint32_t w4[kStuffDepth];
+#pragma unroll
+    for (int u = 0; u < kStuffDepth; ++u) {
+        const uint32_t* q = S + 256 * u + 4 * lane;
+        w[u] = *reinterpret_cast<const uint4*>(q);
+        w4[u] = q[4];
+    }
+    const uint32_t c = gid % p.cpi;
+    const uint32_t n = p.chunk_bits[gid] & kCountMask;
+    const uint64_t o = p.bit_off[gid];
+    const uint32_t sbits = (uint32_t)(o & 7u);  // bits of the first owned byte that lie in the predecessor
+    const uint32_t A = (8u - sbits) & 7u;
+    const uint32_t nbytes = (uint32_t)(((o + n) >> 3) - (o >> 3));
+    const uint32_t nm = nbytes - (sbits ? 1u : 0u);  // owned bytes that lie entirely in this chunk
+    uint32_t total = 0;
+    if (sbits != 0 && lane == 0) {
+        const uint32_t pw = (c > 0) ? (p.chunk_bits[gid - 1] >> 24) : 0u;
+        const uint32_t sb = ((pw << A) | (readlane_u32(w[0].x, 0) >> (32u - A))) & 0xFFu;
+        total = (sb == 0xFFu) ? 1u : 0u;
+    }
+    for (uint32_t pass = 0; pass < nm; pass += 1024 * kStuffDepth) {
+        if (pass != 0) {
+#pragma unroll
+            for (int u = 0; u < kStuffDepth; ++u) {
+                const uint32_t* q = S + ((pass >> 2) + 256 * u) + 4 * lane;
+                if (pass + 1024u * u < nm) {  // uniform
+                    w[u] = *reinterpret_cast<const uint4*>(q);
+                    w4[u] = q[4];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kStuffDepth; ++u) {
+            const uint32_t base = pass + 1024u * u;
+            if (base < nm) {  // uniform
+                uint32_t v0 = w[u].x, v1 = w[u].y, v2 = w[u].z, v3 = w[u].w;
+                if (A != 0) {  // uniform
+                    v0 = __builtin_amdgcn_alignbit(w[u].x, w[u].y, 32u - A);
+                    v1 = __builtin_amdgcn_alignbit(w[u].y, w[u].z, 32u - A);
+                    v2 = __builtin_amdgcn_alignbit(w[u].z, w[u].w, 32u - A);
+                    v3 = __builtin_amdgcn_alignbit(w[u].w, w4[u], 32u - A);
+                }
+                uint32_t m0 = ff_flags(v0), m1 = ff_flags(v1), m2 = ff_flags(v2), m3 = ff_flags(v3);
+                if (base + 1024 > nm) {  // uniform: the last step, some bytes lie behind the chunk's last whole byte
+                    const uint32_t j = base + 16u * (uint32_t)lane;
+                    const int nv = (j < nm) ? (int)min(16u, nm - j) : 0;
+                    auto keep = [&](int nb) { return nb >= 4 ? 0xFFFFFFFFu : nb <= 0 ? 0u : ~(0xFFFFFFFFu >> (8 * nb)); };
+                    m0 &= keep(nv); m1 &= keep(nv - 4); m2 &= keep(nv - 8); m3 &= keep(nv - 12);
+                }
+                total += __popc(m0) + __popc(m1) + __popc(m2) + __popc(m3);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d);
+    if (lane == 0) p.chunk_ff[gid] = total;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -921,12 +1026,16 @@ hipError_t launch_scan(const ScanParams& p, uint32_t n_images, hipStream_t s) {
 }
 
 hipError_t launch_stuff_count(const StuffParams& p, uint32_t n_images, hipStream_t s) {
-    hipLaunchKernelGGL((k_stuff<false>), dim3(n_images * p.cpi), dim3(64), 0, s, p);
+    const uint32_t n_chunks = n_images * p.cpi;
+    hipLaunchKernelGGL(k_stuff_count, dim3((n_chunks + kStuffWaves - 1) / kStuffWaves), dim3(64 * kStuffWaves), 0, s, p,
+                       n_chunks);
     return hipGetLastError();
 }
 
 hipError_t launch_stuff_write(const StuffParams& p, uint32_t n_images, hipStream_t s) {
-    hipLaunchKernelGGL((k_stuff<true>), dim3(n_images * p.cpi), dim3(64), 0, s, p);
+    const uint32_t n_chunks = n_images * p.cpi;
+    hipLaunchKernelGGL((k_stuff<true>), dim3((n_chunks + kStuffWaves - 1) / kStuffWaves), dim3(64 * kStuffWaves), 0, s, p,
+                       n_chunks);
     return hipGetLastError();
 }
 
