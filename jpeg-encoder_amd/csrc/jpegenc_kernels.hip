@@ -6,8 +6,8 @@
 //                    lane's bit string stays in registers, the bit strings are concatenated in LDS and
 //                    written once, as the chunk's bit stream, to its workspace slot.
 //   k_scan           exclusive prefix of the per-chunk bit counts (and later of the 0xFF counts) per image.
-//   k_stuff<false>   counts the complete 0xFF bytes each chunk owns once its global bit phase is known.
-//   k_stuff<true>    shifts every chunk stream to its global position, inserts 0x00 after 0xFF, writes
+//   k_stuff_count    counts the complete 0xFF bytes each chunk owns once its global bit phase is known.
+//   k_stuff_write    shifts every chunk stream to its global position, inserts 0x00 after 0xFF, writes
 //                    the 32-bit words and the end-of-file result.
 //
 // Reference arithmetic reproduced here (paths relative to the reference tree):
@@ -55,6 +55,20 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Inclusive prefix sum over the wave with DPP moves: shifts by 1, 2, 4, 8 inside each row of 16 lanes
+// (lanes without a source add 0), then lane 15 of rows 0 and 2 into rows 1 and 3, then lane 31 into rows
+// 2 and 3.
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+    return (uint32_t)x;
 }
 
 __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int l) {
@@ -693,7 +707,7 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_stuff: one wavefront per chunk, 16 stream bytes per lane and step.
+// Stuffing (k_stuff_count, k_stuff_write): one wavefront per chunk, 16 stream bytes per lane and step.
 // The image's unstuffed stream is the concatenation of its chunk streams; chunk c covers global bits
 // [o, o+n).  A byte of that stream is owned by the chunk holding its last bit, so chunk c owns bytes
 // [o>>3, (o+n)>>3): its first byte may begin in the previous chunk (every chunk has >= 1152 bits, so
@@ -701,218 +715,10 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams p) {
 // after them (ff_checker.sv:96-179).  Output byte i of the stuffed stream lives in word i/4 at bits
 // 31-8*(i%4), i.e. at byte address i^3 of a little-endian word array.
 // ------------------------------------------------------------------------------------------------
-struct __attribute__((packed, aligned(4))) Words4 {
-    uint32_t w[4];
-};
-
-// bit 7 of every byte of the result is set iff that byte of v is 0xFF
-__device__ __forceinline__ uint32_t ff_mask(uint32_t v) {
-    uint32_t a = v & (v << 4);
-    a &= a << 2;
-    a &= a << 1;
-    return a & 0x80808080u;
-}
-
 constexpr int kStageBytes = 2048 + 64;  // one step: <= 1024 bytes, doubled by stuffing, + residual
 
-constexpr int kStuffWaves = 4;
+constexpr int kStuffWaves = 4;  // independent waves per workgroup, one chunk each
 constexpr int kStuffDepth = 5;  // steps whose loads are in flight together
-
-template <bool WRITE>
-__global__ __launch_bounds__(64 * kStuffWaves) void k_stuff(StuffParams p, uint32_t n_chunks) {
-    // kStuffWaves independent waves per workgroup, one chunk each: nothing is shared between them
-    __shared__ __attribute__((aligned(16))) uint8_t stage_all[kStuffWaves][WRITE ? kStageBytes : 16];
-    uint8_t* const stage = stage_all[threadIdx.x >> 6];
-    const int lane = threadIdx.x & 63;
-    const uint32_t gid = blockIdx.x * kStuffWaves + (threadIdx.x >> 6);
-    if (gid >= n_chunks) return;
-    const uint32_t img = gid / p.cpi;
-    const uint32_t c = gid - img * p.cpi;
-    const uint32_t n = p.chunk_bits[gid] & kCountMask;
-    const uint64_t o = p.bit_off[gid];
-    const uint32_t* S = p.slots + (uint64_t)gid * kSlotWords;
-    // the predecessor's last 8 bits stand in for word -1: only the low o & 7 bits of it are used
-    const uint32_t pw = (c > 0) ? (p.chunk_bits[gid - 1] >> 24) : 0u;
-    const uint64_t q_first = o >> 3;
-    const uint64_t q_end = (o + n) >> 3;
-    const uint32_t nbytes = (uint32_t)(q_end - q_first);
-    // The first owned byte starts at local bit -(o & 7).  All lanes share the shift s within a word;
-    // lane t's 16 bytes start at word W0 + 4t (W0 = -1 when the first byte begins in the predecessor).
-    const uint32_t s = (32u - (uint32_t)(o & 7u)) & 31u;
-    const int W0 = (o & 7u) ? -1 : 0;
-
-    uint32_t* out_words = nullptr;
-    uint8_t* out_bytes = nullptr;
-    uint64_t wbase = 0;   // global word index of stage[0]
-    uint32_t fill = 0;    // bytes in the stage (uniform)
-    uint32_t head = 0;    // leading bytes of the stage's first word that belong to the previous chunk
-    if constexpr (WRITE) {
-        out_words = p.words_out + (uint64_t)img * p.out_stride;
-        out_bytes = reinterpret_cast<uint8_t*>(out_words);
-        const uint64_t pos0 = q_first + p.ff_off[gid];  // stuffed byte offset of the first owned byte
-        wbase = pos0 >> 2;
-        head = fill = (uint32_t)(pos0 & 3u);
-    }
-    const uint64_t cap_bytes = p.cap_words * 4;
-    uint32_t ff_total = 0;
-
-    auto flush = [&](bool final_pad) {
-        // stores the complete words of the stage; keeps the residual bytes for the next step
-        const uint32_t nwords = final_pad ? ((fill + 3u) >> 2) : (fill >> 2);
-        for (uint32_t i = lane; i < nwords; i += 64) {
-            const uint32_t raw = reinterpret_cast<const uint32_t*>(stage)[i];
-            const uint64_t gw = wbase + i;
-            if (i == 0 && head) {  // word shared with the previous chunk: only our bytes
-                for (uint32_t b = head; b < 4; ++b) {
-                    const uint64_t ga = gw * 4 + b;
-                    if (ga < cap_bytes) out_bytes[ga ^ 3] = stage[b];
-                }
-            } else if (gw < p.cap_words) {
-                out_words[gw] = __builtin_bswap32(raw);
-            }
-        }
-        wave_sync();
-        if (nwords) {
-            const uint32_t rest = final_pad ? 0u : (fill & 3u);
-            if (lane < rest) stage[lane] = stage[nwords * 4 + lane];  // reads and writes are disjoint words
-            wbase += nwords;
-            fill = rest;
-            head = 0;
-        }
-        wave_sync();
-    };
-
-    // One step's raw words of this lane: 16 bytes from word W0 + (base + 16 * lane) / 4 and the word after
-    // them.  The next step's words are requested before the current step is worked on.
-    struct Raw {
-        Words4 q;
-        uint32_t w4;
-    };
-    auto fetch = [&](uint32_t base) {
-        Raw r;
-        r.q.w[0] = r.q.w[1] = r.q.w[2] = r.q.w[3] = r.w4 = 0;
-        const uint32_t j = base + (uint32_t)lane * 16u;
-        if (j < nbytes) {
-            const int wi = W0 + (int)(j >> 2);
-            if (wi >= 0) {
-                r.q = *reinterpret_cast<const Words4*>(S + wi);
-            } else {  // only lane 0 of the first step
-                r.q.w[0] = pw; r.q.w[1] = S[0]; r.q.w[2] = S[1]; r.q.w[3] = S[2];
-            }
-            r.w4 = S[wi + 4];
-        }
-        return r;
-    };
-    Raw nxt = fetch(0);
-    for (uint32_t base = 0; base < nbytes; base += 1024) {
-        const uint32_t j = base + (uint32_t)lane * 16u;
-        const int nvalid = (j < nbytes) ? (int)min(16u, nbytes - j) : 0;
-        const Raw cur = nxt;
-        if (base + 1024 < nbytes) nxt = fetch(base + 1024);
-        uint32_t v[4] = {0, 0, 0, 0};
-        if (nvalid > 0) {
-            const Words4& q = cur.q;
-            const uint32_t w4 = cur.w4;
-            if (s == 0) {
-                v[0] = q.w[0]; v[1] = q.w[1]; v[2] = q.w[2]; v[3] = q.w[3];
-            } else {
-                v[0] = __builtin_amdgcn_alignbit(q.w[0], q.w[1], 32u - s);
-                v[1] = __builtin_amdgcn_alignbit(q.w[1], q.w[2], 32u - s);
-                v[2] = __builtin_amdgcn_alignbit(q.w[2], q.w[3], 32u - s);
-                v[3] = __builtin_amdgcn_alignbit(q.w[3], w4, 32u - s);
-            }
-        }
-        uint32_t m[4];
-        uint32_t cnt = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int nb = nvalid - 4 * i;  // valid bytes of word i
-            const uint32_t keep = nb >= 4 ? 0xFFFFFFFFu : nb <= 0 ? 0u : ~(0xFFFFFFFFu >> (8 * nb));
-            m[i] = ff_mask(v[i]) & keep;
-            cnt += __popc(m[i]);
-        }
-        if constexpr (!WRITE) {
-            ff_total += cnt;
-        } else {
-            uint32_t it_ff;
-            const uint32_t pre = wave_excl_scan_u32(cnt, lane, &it_ff);
-            uint32_t a = fill + (j - base) + pre;  // stage offset of this lane's first byte
-            if (nvalid == 16 && cnt == 0) {
-                uint32_t t[4] = {__builtin_bswap32(v[0]), __builtin_bswap32(v[1]), __builtin_bswap32(v[2]),
-                                 __builtin_bswap32(v[3])};
-                __builtin_memcpy(&stage[a], t, 16);  // byte-aligned 16-byte store
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int nb = nvalid - 4 * i;
-                    if (nb >= 4 && m[i] == 0) {
-                        const uint32_t t = __builtin_bswap32(v[i]);
-                        __builtin_memcpy(&stage[a], &t, 4);
-                        a += 4;
-                    } else {
-                        for (int b = 0; b < 4 && b < nb; ++b) {
-                            stage[a++] = (uint8_t)(v[i] >> (24 - 8 * b));
-                            if (m[i] & (0x80000000u >> (8 * b))) stage[a++] = 0;
-                        }
-                    }
-                }
-            }
-            fill += min(1024u, nbytes - base) + it_ff;
-            wave_sync();
-            flush(false);
-        }
-    }
-
-    if constexpr (!WRITE) {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) ff_total += __shfl_xor(ff_total, d);
-        if (lane == 0) p.chunk_ff[gid] = ff_total;
-    } else {
-        const bool last = (c == p.cpi - 1);
-        if (!last) {
-            // bytes after the last whole word belong to a word shared with the next chunk
-            if ((uint32_t)lane >= head && (uint32_t)lane < fill) {
-                const uint64_t ga = wbase * 4 + lane;
-                if (ga < cap_bytes) out_bytes[ga ^ 3] = stage[lane];
-            }
-        } else {
-            // end of file: the incomplete last byte is never stuffed; the residual bits are presented
-            // left-aligned in one more word with their count (ff_checker.sv:289-360, functional)
-            const uint64_t total_bits = o + n;
-            const uint32_t rem = (uint32_t)(total_bits & 7u);
-            const uint64_t stuffed_bytes = wbase * 4 + fill;
-            if (lane == 0) {
-                uint32_t f = fill;
-                if (rem) {
-                    // the last rem bits of the chunk stream, left-aligned in a byte
-                    const uint32_t l = n - rem, wi = l >> 5, sh = l & 31u;
-                    const uint32_t w32 = sh ? __builtin_amdgcn_alignbit(S[wi], S[wi + 1], 32u - sh) : S[wi];
-                    const uint32_t vb = w32 >> 24;
-                    stage[f++] = (uint8_t)(vb & (0xFFu << (8u - rem)));
-                }
-                while (f & 3u) stage[f++] = 0;
-            }
-            fill = (fill + (rem ? 1u : 0u) + 3u) & ~3u;
-            wave_sync();
-            const uint32_t tail_idx = (uint32_t)(((stuffed_bytes * 8 + rem) >> 5) - wbase);  // word holding the residual
-            const uint32_t tail_raw = (tail_idx * 4 < fill) ? reinterpret_cast<const uint32_t*>(stage)[tail_idx] : 0u;
-            flush(true);
-            if (lane == 0) {
-                const uint64_t sbits = stuffed_bytes * 8 + rem;
-                jpegenc_result r;
-                r.n_full_words = sbits >> 5;
-                r.total_bits_unstuffed = total_bits;
-                r.total_bytes_stuffed = stuffed_bytes;
-                r.tail_bits = (uint8_t)(sbits & 31u);
-                r.eof_partial_ready = r.tail_bits ? 1 : 0;
-                r.tail_word = r.tail_bits ? __builtin_bswap32(tail_raw) : 0u;
-                const uint64_t need = r.n_full_words + (r.tail_bits ? 1 : 0);
-                r.status = (need > p.cap_words) ? (int16_t)JPEGENC_E_TOO_SMALL : (int16_t)JPEGENC_OK;
-                p.results[img] = r;
-            }
-        }
-    }
-}
 
 // bit 7 of every byte of the result is set iff that byte of v is 0xFF: the low seven bits plus one carry
 // into bit 7 exactly when they are all ones, and never beyond the byte
@@ -922,7 +728,7 @@ __device__ __forceinline__ uint32_t ff_flags(uint32_t v) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_stuff_count: number of 0xFF bytes each chunk owns (see k_stuff for the ownership rule).  One wave
+// k_stuff_count: number of 0xFF bytes each chunk owns (ownership rule above).  One wave
 // per chunk, 16 stream bytes per lane and step.  The byte that begins in the predecessor is taken on
 // its own; the bytes after it start A = (8 - o % 8) % 8 bits into the chunk's stream, so lane t's four
 // shifted words come from one aligned 16-byte load at word 256 * step + 4 * t and the word behind it.
@@ -996,6 +802,223 @@ __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_count(StuffParams p,
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_stuff_write: shifts every chunk stream to its byte phase, inserts 0x00 after 0xFF and writes the
+// 32-bit words; the last chunk of an image also writes the end-of-file result.  Same walk over the
+// chunk as k_stuff_count.  The stuffed bytes of a step are laid out in stream order in an LDS stage
+// (one per wave) and leave it as whole words; the bytes of a word shared with a neighbouring chunk are
+// stored one by one.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_write(StuffParams p, uint32_t n_chunks) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage_all[kStuffWaves][kStageBytes];
+    uint8_t* const stage = stage_all[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    const uint32_t gid = blockIdx.x * kStuffWaves + (threadIdx.x >> 6);
+    if (gid >= n_chunks) return;
+    const uint32_t* S = p.slots + (uint64_t)gid * kSlotWords;
+    uint4 w[kStuffDepth];
+    uint32_t w4[kStuffDepth];
+#pragma unroll
+    for (int u = 0; u < kStuffDepth; ++u) {  // ahead of the counts and offsets, as in k_stuff_count
+        const uint32_t* q = S + 256 * u + 4 * lane;
+        w[u] = *reinterpret_cast<const uint4*>(q);
+        w4[u] = q[4];
+    }
+    const uint32_t img = gid / p.cpi;
+    const uint32_t c = gid - img * p.cpi;
+    const uint32_t n = p.chunk_bits[gid] & kCountMask;
+    const uint64_t o = p.bit_off[gid];
+    const uint64_t q_first = o >> 3;
+    const uint32_t sbits = (uint32_t)(o & 7u);
+    const uint32_t A = (8u - sbits) & 7u;
+    const uint32_t nbytes = (uint32_t)(((o + n) >> 3) - q_first);
+    const uint32_t nm = nbytes - (sbits ? 1u : 0u);
+
+    uint32_t* const out_words = p.words_out + (uint64_t)img * p.out_stride;
+    uint8_t* const out_bytes = reinterpret_cast<uint8_t*>(out_words);
+    const uint64_t cap_bytes = p.cap_words * 4;
+    const uint64_t pos0 = q_first + p.ff_off[gid];  // stuffed byte offset of the first owned byte
+    uint64_t wbase = pos0 >> 2;                     // global word index of stage[0]
+    uint32_t head = (uint32_t)(pos0 & 3u);          // leading bytes of the stage's first word that belong to the previous chunk
+    uint32_t fill = head;                           // bytes in the stage (uniform)
+
+    if (sbits != 0) {  // the byte that begins in the predecessor: its last 8 bits travel with its bit count
+        const uint32_t pw = (c > 0) ? (p.chunk_bits[gid - 1] >> 24) : 0u;
+        const uint32_t sb = ((pw << A) | (readlane_u32(w[0].x, 0) >> (32u - A))) & 0xFFu;
+        if (lane == 0) {
+            stage[fill] = (uint8_t)sb;
+            stage[fill + 1] = 0;
+        }
+        fill += (sb == 0xFFu) ? 2u : 1u;
+    }
+
+    auto flush = [&](bool final_pad) {
+        // stores the complete words of the stage, four per lane and turn; keeps the residual bytes for
+        // the next step
+        const uint32_t nwords = final_pad ? ((fill + 3u) >> 2) : (fill >> 2);
+        for (uint32_t i = 4u * lane; i < nwords; i += 256) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(stage + 4 * i);
+            const uint64_t gw = wbase + i;
+            const uint32_t t[4] = {__builtin_bswap32(raw.x), __builtin_bswap32(raw.y), __builtin_bswap32(raw.z),
+                                   __builtin_bswap32(raw.w)};
+            if (i + 4 <= nwords && gw + 4 <= p.cap_words && !(i == 0 && head)) {
+                __builtin_memcpy(out_words + gw, t, 16);  // word-aligned 16-byte store
+            } else {
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    if (i + k >= nwords) break;
+                    if (i + k == 0 && head) {  // word shared with the previous chunk: only our bytes
+                        for (uint32_t b = head; b < 4; ++b) {
+                            const uint64_t ga = gw * 4 + b;
+                            if (ga < cap_bytes) out_bytes[ga ^ 3] = stage[b];
+                        }
+                    } else if (gw + k < p.cap_words) {
+                        out_words[gw + k] = t[k];
+                    }
+                }
+            }
+        }
+        wave_sync();
+        if (nwords) {
+            const uint32_t rest = final_pad ? 0u : (fill & 3u);
+            if (lane < rest) stage[lane] = stage[nwords * 4 + lane];  // reads and writes are disjoint words
+            wbase += nwords;
+            fill = rest;
+            head = 0;
+        }
+        wave_sync();
+    };
+
+    // One word holding at least one 0xFF (flags m), all four bytes valid, to stage offset `at`.  Every byte
+    // goes out as the pair (byte, 0x00): the zero is the stuffing when the byte is 0xFF and is
+    // overwritten by the next byte's pair otherwise.  The last byte of a lane's last word must not
+    // write beyond the lane's bytes: it is stored alone unless it is 0xFF.
+    auto ff_word = [&](uint32_t at, uint32_t v, uint32_t m, bool lane_end) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint16_t pair = (uint16_t)((v >> (24 - 8 * b)) & 0xFFu);
+            const uint32_t f = (m >> (31 - 8 * b)) & 1u;
+            if (b < 3 || !lane_end || f)
+                __builtin_memcpy(&stage[at], &pair, 2);
+            else
+                stage[at] = (uint8_t)pair;
+            at += 1u + f;
+        }
+    };
+
+    for (uint32_t pass = 0; pass < nm; pass += 1024 * kStuffDepth) {
+        if (pass != 0) {
+#pragma unroll
+            for (int u = 0; u < kStuffDepth; ++u) {
+                const uint32_t* q = S + ((pass >> 2) + 256 * u) + 4 * lane;
+                if (pass + 1024u * u < nm) {  // uniform
+                    w[u] = *reinterpret_cast<const uint4*>(q);
+                    w4[u] = q[4];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kStuffDepth; ++u) {
+            const uint32_t base = pass + 1024u * u;
+            if (base >= nm) break;  // uniform
+            const uint32_t j = base + 16u * (uint32_t)lane;
+            const int nvalid = (j < nm) ? (int)min(16u, nm - j) : 0;
+            uint32_t v[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+            if (A != 0) {  // uniform
+                v[0] = __builtin_amdgcn_alignbit(w[u].x, w[u].y, 32u - A);
+                v[1] = __builtin_amdgcn_alignbit(w[u].y, w[u].z, 32u - A);
+                v[2] = __builtin_amdgcn_alignbit(w[u].z, w[u].w, 32u - A);
+                v[3] = __builtin_amdgcn_alignbit(w[u].w, w4[u], 32u - A);
+            }
+            uint32_t m[4] = {ff_flags(v[0]), ff_flags(v[1]), ff_flags(v[2]), ff_flags(v[3])};
+            const bool partial = base + 1024 > nm;  // uniform: the chunk's last step, some lanes hold fewer than 16 bytes
+            if (partial) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int nb = nvalid - 4 * i;  // valid bytes of word i
+                    m[i] &= nb >= 4 ? 0xFFFFFFFFu : nb <= 0 ? 0u : ~(0xFFFFFFFFu >> (8 * nb));
+                }
+            }
+            const uint32_t cnt = __popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]);
+            const uint32_t incl = wave_incl_scan_dpp(cnt);
+            const uint32_t it_ff = readlane_u32(incl, 63);
+            uint32_t a = fill + 16u * (uint32_t)lane + (incl - cnt);  // stage offset of this lane's first byte
+            if (nvalid == 16 && cnt == 0) {
+                uint32_t t[4] = {__builtin_bswap32(v[0]), __builtin_bswap32(v[1]), __builtin_bswap32(v[2]),
+                                 __builtin_bswap32(v[3])};
+                __builtin_memcpy(&stage[a], t, 16);  // byte-aligned 16-byte store
+            } else if (nvalid == 16) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (m[i] == 0) {
+                        const uint32_t t = __builtin_bswap32(v[i]);
+                        __builtin_memcpy(&stage[a], &t, 4);
+                    } else {
+                        ff_word(a, v[i], m[i], i == 3);
+                    }
+                    a += 4u + __popc(m[i]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int nb = nvalid - 4 * i;
+                    for (int b = 0; b < 4 && b < nb; ++b) {
+                        stage[a++] = (uint8_t)(v[i] >> (24 - 8 * b));
+                        if (m[i] & (0x80000000u >> (8 * b))) stage[a++] = 0;
+                    }
+                }
+            }
+            fill += min(1024u, nm - base) + it_ff;
+            wave_sync();
+            flush(false);
+        }
+    }
+
+    const bool last = (c == p.cpi - 1);
+    if (!last) {
+        // bytes after the last whole word belong to a word shared with the next chunk
+        if ((uint32_t)lane >= head && (uint32_t)lane < fill) {
+            const uint64_t ga = wbase * 4 + lane;
+            if (ga < cap_bytes) out_bytes[ga ^ 3] = stage[lane];
+        }
+    } else {
+        // end of file: the incomplete last byte is never stuffed; the residual bits are presented
+        // left-aligned in one more word with their count (ff_checker.sv:289-360, functional)
+        const uint64_t total_bits = o + n;
+        const uint32_t rem = (uint32_t)(total_bits & 7u);
+        const uint64_t stuffed_bytes = wbase * 4 + fill;
+        if (lane == 0) {
+            uint32_t f = fill;
+            if (rem) {
+                // the last rem bits of the chunk stream, left-aligned in a byte
+                const uint32_t l = n - rem, wi = l >> 5, sh = l & 31u;
+                const uint32_t w32 = sh ? __builtin_amdgcn_alignbit(S[wi], S[wi + 1], 32u - sh) : S[wi];
+                const uint32_t vb = w32 >> 24;
+                stage[f++] = (uint8_t)(vb & (0xFFu << (8u - rem)));
+            }
+            while (f & 3u) stage[f++] = 0;
+        }
+        fill = (fill + (rem ? 1u : 0u) + 3u) & ~3u;
+        wave_sync();
+        const uint32_t tail_idx = (uint32_t)(((stuffed_bytes * 8 + rem) >> 5) - wbase);  // word holding the residual
+        const uint32_t tail_raw = (tail_idx * 4 < fill) ? reinterpret_cast<const uint32_t*>(stage)[tail_idx] : 0u;
+        flush(true);
+        if (lane == 0) {
+            const uint64_t sbits_total = stuffed_bytes * 8 + rem;
+            jpegenc_result r;
+            r.n_full_words = sbits_total >> 5;
+            r.total_bits_unstuffed = total_bits;
+            r.total_bytes_stuffed = stuffed_bytes;
+            r.tail_bits = (uint8_t)(sbits_total & 31u);
+            r.eof_partial_ready = r.tail_bits ? 1 : 0;
+            r.tail_word = r.tail_bits ? __builtin_bswap32(tail_raw) : 0u;
+            const uint64_t need = r.n_full_words + (r.tail_bits ? 1 : 0);
+            r.status = (need > p.cap_words) ? (int16_t)JPEGENC_E_TOO_SMALL : (int16_t)JPEGENC_OK;
+            p.results[img] = r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 template <int ALIGN, bool QUANT>
@@ -1034,7 +1057,7 @@ hipError_t launch_stuff_count(const StuffParams& p, uint32_t n_images, hipStream
 
 hipError_t launch_stuff_write(const StuffParams& p, uint32_t n_images, hipStream_t s) {
     const uint32_t n_chunks = n_images * p.cpi;
-    hipLaunchKernelGGL((k_stuff<true>), dim3((n_chunks + kStuffWaves - 1) / kStuffWaves), dim3(64 * kStuffWaves), 0, s, p,
+    hipLaunchKernelGGL(k_stuff_write, dim3((n_chunks + kStuffWaves - 1) / kStuffWaves), dim3(64 * kStuffWaves), 0, s, p,
                        n_chunks);
     return hipGetLastError();
 }
