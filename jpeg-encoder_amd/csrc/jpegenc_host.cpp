@@ -28,7 +28,7 @@ void build_htab(uint32_t out[kHtabEntries]) {
             if (size == 0 && (sym != JPEGENC_SYM_ZRL || eob)) continue;
             const uint32_t code = JPEGENC_AC_CODE[idx];
             const uint32_t len = JPEGENC_AC_LEN[idx];
-            out[eob * 256 + sym] = ((len + size) << 27) | (code << size);
+            out[((sym >> 4) << 5) | (eob << 4) | size] = ((len + size) << 27) | (code << size);
         }
     {
         const int idx = JPEGENC_AC_RUN_CODE[JPEGENC_SYM_EOB];

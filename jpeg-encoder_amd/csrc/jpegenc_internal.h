@@ -18,9 +18,9 @@ constexpr int kSlotWords = kChunkMcus * kMaxMcuWords;  // 9984 words = 39,936 B
 
 // Packed Huffman table in LDS: entry = (total_length << 27) | (code << size), total_length = code length
 // + amplitude bits; 0 = nothing to emit.
-//   [0, 512)   AC, index = eob << 8 | run << 4 | size.  (run <= 14, size 0) is a zero coefficient inside a
-//              run: nothing; (run 15, size 0) is the 16th zero: ZRL in the eob = 0 half, nothing in the
-//              eob = 1 half (rtl/4_huffman/cr_huff.sv:558).
+//   [0, 512)   AC, index = run << 5 | eob << 4 | size.  (run <= 14, size 0) is a zero coefficient inside
+//              a run: nothing; (run 15, size 0) is the 16th zero: ZRL in the eob = 0 entries, nothing in the
+//              eob = 1 entries (rtl/4_huffman/cr_huff.sv:558).
 //   [512]      EOB
 //   [528, 540) DC by size
 constexpr int kHtabEntries = 544;

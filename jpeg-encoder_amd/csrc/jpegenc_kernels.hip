@@ -309,13 +309,13 @@ __device__ __forceinline__ void encode_block(const int (&blk)[64], int dc_pred, 
     const int t67 = o6 | o7;
     const int t47 = o4 | o5 | t67;
     // end_of_block as a table-index bit (256 = set), per block_counter range (cr_huff.sv:213-231)
-    const uint32_t eob_a = ((o2 | o3 | t47) == 0) ? 256u : 0u;  // block_counter < 32
-    const uint32_t eob_b = (t47 == 0) ? 256u : 0u;              // block_counter < 48
+    const uint32_t eob_a = ((o2 | o3 | t47) == 0) ? 16u : 0u;  // block_counter < 32
+    const uint32_t eob_b = (t47 == 0) ? 16u : 0u;              // block_counter < 48
     // block_counter <= 64: groups 7,8 -- except in cb_huff, where `6'd64` is 0 and the branch that
     // sets end_of_block to 1 always wins (cb_huff.sv:238-243)
-    const uint32_t eob_c = (cb_eob_quirk || t67 == 0) ? 256u : 0u;
+    const uint32_t eob_c = (cb_eob_quirk || t67 == 0) ? 16u : 0u;
 
-    uint32_t r4 = 0;  // run << 4
+    uint32_t r5 = 0;  // run << 5
 #pragma unroll
     for (int k = 1; k <= 62; ++k) {
         const int v = blk[kZZ[k]];
@@ -324,16 +324,17 @@ __device__ __forceinline__ void encode_block(const int (&blk)[64], int dc_pred, 
         const uint32_t size = mag_bits(lead);
         // a run of 15 zeros cannot complete before k = 16, so the flag only matters from there on
         const uint32_t eob = (k < 16) ? 0u : (k + 2 < 32) ? eob_a : (k + 2 < 48) ? eob_b : eob_c;
-        const uint32_t ent = htab[r4 | size | eob];
+        const uint32_t ent = htab[r5 | size | eob];
         bw_emit<GUARD>(bw, (ent & 0x7FFFFFFu) | amp_bits(t, size), ent >> 27, priv);
-        // zero coefficient (lead == -1): run + 1 modulo 16; otherwise the run restarts
-        r4 = (r4 + 16u) & (uint32_t)(lead >> 31) & 0xF0u;
+        // zero coefficient (lead == -1, all ones): run + 1 modulo 16; otherwise the run restarts (lead is
+        // at most 31 then and has no bit in common with the run field)
+        r5 = (r5 + 32u) & (uint32_t)lead & 0x1E0u;
     }
     {
         const int v = blk[63];
         const int t = amp_src(v);
         const uint32_t size = mag_bits(lead_bits(t));
-        const uint32_t ent = htab[(v != 0) ? (r4 | size) : (uint32_t)kHtabEob];
+        const uint32_t ent = htab[(v != 0) ? (r5 | size) : (uint32_t)kHtabEob];
         bw_emit<GUARD>(bw, (ent & 0x7FFFFFFu) | amp_bits(t, size), ent >> 27, priv);
     }
 }
