@@ -584,12 +584,7 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
             const uint32_t nmax = wave_max_u32(nd);             // uniform, <= kOwnWords
             uint32_t own[kOwnWords];
 #pragma unroll
-            for (int t0 = 0; t0 < kOwnWords; t0 += 8) {
-                if ((uint32_t)t0 < nmax) {
-#pragma unroll
-                    for (int t = t0; t < t0 + 8; ++t) own[t] = priv[base + 1 + t];
-                }
-            }
+            for (int t = 0; t < kOwnWords; ++t) own[t] = priv[base + 1 + t];
             wave_sync();
             for (uint32_t i = lane; i < ((gtotal + 31u) >> 5); i += 64) priv[i] = 0u;
             wave_sync();
