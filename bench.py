@@ -33,25 +33,27 @@ def parse_args():
     ap.add_argument("--content", choices=["natural", "noise"], default="natural")
     ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the batch timed on the CPU oracle")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--quant", type=int, default=1, help="every quantiser table entry (1: the RTL default)")
     ap.add_argument("--ws-mb", type=int, default=0, help="workspace limit in MiB (0: library default)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     return ap.parse_args()
 
 
-def cpu_baseline(frames_np, gpu_words, gpu_res, n_threads):
+def cpu_baseline(frames_np, gpu_words, gpu_res, n_threads, qtabs=None):
     """Times the CPU oracle (a scalar C++ port of the RTL arithmetic) on a bounded sample of the same
     frames, one frame per thread, and checks its output against the GPU's, byte for byte."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as O
     O.lib()
+    cfg = O.default_config(qtabs=qtabs)
     n = len(frames_np)
     # single thread on a quarter of the sample
     n1 = max(1, n // 4)
     t0 = time.perf_counter()
     for i in range(n1):
-        O.encode(frames_np[i])
+        O.encode(frames_np[i], cfg)
     t1 = time.perf_counter() - t0
     px = frames_np[0].shape[0] * frames_np[0].shape[1]
     single = n1 * px / t1 / 1e6
@@ -59,7 +61,7 @@ def cpu_baseline(frames_np, gpu_words, gpu_res, n_threads):
 
     def work(k):
         for i in range(k, n, n_threads):
-            out[i] = O.encode(frames_np[i])  # ctypes releases the GIL during the call
+            out[i] = O.encode(frames_np[i], cfg)  # ctypes releases the GIL during the call
 
     threads = [threading.Thread(target=work, args=(k,)) for k in range(n_threads)]
     t0 = time.perf_counter()
@@ -116,7 +118,8 @@ def main():
     results = torch.zeros((nf, 32), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
 
-    enc = pkg.JpegTop(device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    qtabs = None if args.quant == 1 else [[args.quant] * 64] * 3
+    enc = pkg.JpegTop(qtabs=qtabs, device=local_rank, stream=torch.cuda.current_stream().cuda_stream)
 
     if args.ws_mb:
         enc.set_workspace_limit(args.ws_mb << 20)
@@ -159,9 +162,10 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-        "config": {"workload": "%d x %dx%d RGB frames per GPU, %s content, RTL default (all-ones) quant tables; "
+        "config": {"workload": "%d x %dx%d RGB frames per GPU, %s content, %s quant tables; "
                                "8 GPUs = the 8192-frame 1080p configuration, sharded by image"
-                               % (nf, w, h, "natural-like" if args.content == "natural" else "uniform-noise"),
+                               % (nf, w, h, "natural-like" if args.content == "natural" else "uniform-noise",
+                                  "RTL default (all-ones)" if args.quant == 1 else "all-%d" % args.quant),
                    "frames_per_gpu": nf, "width": w, "height": h, "sharding": "independent images, no collective"},
         "all_images_ok": ok, "out_bytes_per_pixel": round(out_bytes_per_px, 4),
     }
@@ -194,7 +198,7 @@ def main():
             frames_np = frames[:n_cpu].cpu().numpy()
             k_max = int((res["n_full_words"][:n_cpu] + 1).max())
             gw = words[:n_cpu, :min(cap_words, k_max)].cpu().numpy().view(np.uint32)
-            line["cpu_baseline"] = cpu_baseline(list(frames_np), gw, res[:n_cpu], args.cpu_threads)
+            line["cpu_baseline"] = cpu_baseline(list(frames_np), gw, res[:n_cpu], args.cpu_threads, qtabs)
         print(json.dumps(line))
     enc.close()
     if world > 1:

@@ -398,7 +398,7 @@ __device__ __forceinline__ CompCoef comp_coef(int comp) {
 
 // quantiser (y_quantizer.sv:58, 74, 106): 11-bit result of (F * (4096/Q) + 2048) >> 12; the 23-bit
 // product register only drops bits that the 11-bit result does not see.
-__device__ __forceinline__ int quant(int f, int qm) { return sext11((f * qm + 2048) >> 12); }
+__device__ __forceinline__ int quant(int f, int qm) { return sext11((__mul24(f, qm) + 2048) >> 12); }
 
 // DC coefficient of one component of the MCU *before* this chunk, computed by the whole wave (lane =
 // pixel): needed as the DC predictor of lane 0.  Same arithmetic as dct8x8 restricted to k = j = 0.
