@@ -648,7 +648,7 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
                 const uint32_t hi = (t >= 1 && t - 1 < nw) ? priv[t - 1] : 0u;
                 uint32_t w = s ? ((hi << (32u - s)) | (lo >> s)) : lo;
                 if (t == 0) w |= carry;
-                slot[d0 + t] = w;
+                __builtin_nontemporal_store(w, &slot[d0 + t]);  // streamed: keeps the pixels in L2 for the next component
             }
             const uint32_t nt = chunk_total + gtotal;
             {   // the last 8 bits of the stream so far (a non-empty group has at least 18 bits)
