@@ -78,7 +78,12 @@ def cpu_baseline(frames_np, gpu_words, gpu_res, n_threads, qtabs=None):
         same = (k == len(words) and np.array_equal(gpu_words[i][:k], words)
                 and int(gpu_res[i]["tail_bits"]) == r.tail_bits and int(gpu_res[i]["tail_word"]) == r.tail_word)
         mismatches += 0 if same else 1
+    import shutil
+    sim = next((t for t in ("verilator", "iverilog") if shutil.which(t)), None)
     return dict(value=round(multi, 2), unit="Mpixel/s", cores=n_threads, kind="port",
+                rtl_sim="unavailable (no verilator/iverilog on this host; the RTL does not elaborate either)"
+                if sim is None else "%s present, RTL not built (it does not elaborate)" % sim,
+                host_cpus=os.cpu_count(),
                 sample="%d frames of the timed batch, one frame per thread (C++ oracle, -O2)" % n,
                 single_thread_mpixel_s=round(single, 2), seconds=round(t1 + tm, 2),
                 frames_compared_with_gpu=n, mismatching_frames=mismatches)
