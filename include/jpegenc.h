@@ -108,6 +108,32 @@ int jpegenc_encode_stripes(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int h, p
                            uint32_t flags, uint32_t* words_out, size_t cap_words_per_stripe,
                            jpegenc_result* results);
 
+/* One stream from consecutive segments.  No counterpart in jpeg_top, which codes an image in one
+ * run: these three calls let several GPUs each code a horizontal band (whole block rows) of one
+ * image and still produce, once the bands' words are ORed together at their positions, exactly the
+ * words jpegenc_encode_rgb8 gives for the whole image (jpeg_top.sv:24-27 for the whole feed).  What
+ * couples the bands is what the RTL carries from block to block: the DC predictors
+ * (cr_huff.sv:591-596), the running bit offset (fifo_out.sv:222-243) and the stuffed byte count
+ * (ff_checker.sv:96-179).  Per band, in this order:
+ *   1. jpegenc_segment_encode: codes the band.  With JPEGENC_SEG_CONTINUES the 8 pixel rows above
+ *      `rgb` (rgb - 8*stride ...) must be readable: their last 8x8 block supplies the DC
+ *      predictors.  Returns the band's bit count and its last 8 bits.
+ *   2. jpegenc_segment_count(bit_offset = bits of all bands before this one, prev_tail8 = the last
+ *      8 bits of the band before it, 0 for the first): 0xFF bytes this band owns at that phase.
+ *   3. jpegenc_segment_write(ff_offset = 0xFF bytes of all bands before this one, is_last): writes
+ *      the band's words; words_out[i] is word first_word + i of the whole stream, n_words of them;
+ *      bytes of the first and last word that belong to the neighbouring bands are zero.  The last
+ *      band also fills `result` (host memory) with the whole stream's figures (its tail_word holds
+ *      this band's bytes only: if the band before it shares that word, take it from the ORed words).
+ * `flags`: JPEGENC_HOST_PTRS/JPEGENC_DEVICE_PTRS for rgb resp. words_out, ORed with
+ * JPEGENC_SEG_CONTINUES in step 1 for every band but the first.  The calls synchronise the stream. */
+#define JPEGENC_SEG_CONTINUES 2u
+int jpegenc_segment_encode(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int rows, ptrdiff_t stride, uint32_t flags,
+                           uint64_t* bits, uint32_t* tail8);
+int jpegenc_segment_count(jpegenc_ctx* ctx, uint64_t bit_offset, uint32_t prev_tail8, uint64_t* ff_bytes);
+int jpegenc_segment_write(jpegenc_ctx* ctx, uint64_t ff_offset, int is_last, uint32_t flags, uint32_t* words_out,
+                          size_t cap_words, uint64_t* first_word, uint64_t* n_words, jpegenc_result* result);
+
 /* Port-level protocol, one call per clock edge of interest (jpeg_top.sv:20-27):
  *   jpegenc_reset        = rst
  *   jpegenc_push_pixel   = enable with data_in[23:0] = {B[23:16],G[15:8],R[7:0]}; 64 consecutive

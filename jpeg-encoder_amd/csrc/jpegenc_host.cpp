@@ -98,6 +98,12 @@ struct jpegenc_ctx {
     DevBuf<uint32_t> out_stage;
     DevBuf<jpegenc_result> res_stage;
 
+    // segment API: what jpegenc_segment_encode left in the workspace
+    bool seg_ready = false, seg_counted = false;
+    uint32_t seg_cpi = 0;
+    uint64_t seg_bits = 0, seg_bit_offset = 0, seg_ff = 0;
+    uint32_t seg_prev_tail8 = 0;
+
     // port-level protocol
     std::vector<uint8_t> port_px;
     std::vector<uint32_t> port_words;
@@ -219,6 +225,9 @@ int encode_device(jpegenc_ctx* ctx, const uint8_t* rgb, int n_images, int w, int
         tp.cap_words = cap_words;
         tp.results = results + first;
         tp.cpi = cpi;
+        tp.pred_tail8 = 0;
+        tp.bit_base = tp.ff_base = tp.out_word_base = 0;
+        tp.eof = 1;
         {
             ProfScope ps(ctx, K_STUFF_COUNT);
             HIPCHK(ctx, launch_stuff_count(tp, n, ctx->stream));
@@ -412,6 +421,151 @@ int jpegenc_encode_stripes(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int h, p
     if (rows % 8) return JPEGENC_E_BAD_ARG;
     return jpegenc_encode_batch(ctx, rgb, n_stripes, w, rows, stride, stride * ptrdiff_t(rows), flags, words_out,
                                 cap_words_per_stripe, results);
+}
+
+// ---- one stream from consecutive segments -------------------------------------------------------------
+int jpegenc_segment_encode(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int rows, ptrdiff_t stride, uint32_t flags,
+                           uint64_t* bits, uint32_t* tail8) {
+    if (!ctx || !rgb || !bits || !tail8) return JPEGENC_E_BAD_ARG;
+    if (w <= 0 || rows <= 0 || (w % 8) || (rows % 8) || stride < ptrdiff_t(w) * 3) return JPEGENC_E_BAD_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->seg_ready = ctx->seg_counted = false;
+    const bool continues = (flags & JPEGENC_SEG_CONTINUES) != 0;
+    const uint8_t* d_rgb = rgb;
+    ptrdiff_t d_stride = stride;
+    if (!(flags & JPEGENC_DEVICE_PTRS)) {
+        const size_t row = size_t(w) * 3;
+        const int halo = continues ? 8 : 0;
+        HIPCHK(ctx, ctx->in_stage.reserve(row * size_t(rows + halo)));
+        HIPCHK(ctx, hipMemcpy2DAsync(ctx->in_stage.p, row, rgb - ptrdiff_t(halo) * stride, size_t(stride), row,
+                                     size_t(rows + halo), hipMemcpyHostToDevice, ctx->stream));
+        d_rgb = ctx->in_stage.p + row * size_t(halo);
+        d_stride = ptrdiff_t(row);
+    }
+    const uint32_t mcu_w = uint32_t(w / 8);
+    const uint64_t n_mcu64 = uint64_t(mcu_w) * uint32_t(rows / 8);
+    if (n_mcu64 > 0x7FFFFFFFull) return JPEGENC_E_UNSUPPORTED;
+    const uint32_t cpi = uint32_t((n_mcu64 + kChunkMcus - 1) / kChunkMcus);
+    HIPCHK(ctx, ctx->slots.reserve((size_t(cpi) + 1) * size_t(kSlotWords)));
+    HIPCHK(ctx, ctx->chunk_bits.reserve(cpi));
+    HIPCHK(ctx, ctx->chunk_ff.reserve(cpi));
+    HIPCHK(ctx, ctx->bit_off.reserve(cpi));
+    HIPCHK(ctx, ctx->ff_off.reserve(cpi));
+    EncodeParams ep;
+    ep.rgb = d_rgb;
+    ep.stride = d_stride;
+    ep.image_stride = 0;
+    ep.mcu_w = mcu_w;
+    ep.n_mcu = uint32_t(n_mcu64);
+    ep.cpi = cpi;
+    ep.flags = ctx->flags | (continues ? 4u : 0u);
+    ep.slots = ctx->slots.p;
+    ep.chunk_bits = ctx->chunk_bits.p;
+    ep.htab = ctx->htab.p;
+    ep.qmul = ctx->quant ? ctx->qmul.p : nullptr;
+    // the block row above must be as aligned as the segment's own rows: the stride takes care of that
+    HIPCHK(ctx, launch_encode(ep, 1, pointer_align(d_rgb, d_stride, 0, 1), ctx->stream));
+    ScanParams sp;
+    sp.counts = ctx->chunk_bits.p;
+    sp.prefix = ctx->bit_off.p;
+    sp.cpi = cpi;
+    HIPCHK(ctx, launch_scan(sp, 1, ctx->stream));
+    uint32_t last_count = 0;
+    uint64_t last_off = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&last_count, ctx->chunk_bits.p + (cpi - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&last_off, ctx->bit_off.p + (cpi - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->seg_cpi = cpi;
+    ctx->seg_bits = last_off + (last_count & 0xFFFFFFu);
+    ctx->seg_ready = true;
+    *bits = ctx->seg_bits;
+    *tail8 = last_count >> 24;
+    return JPEGENC_OK;
+}
+
+namespace {
+StuffParams segment_params(jpegenc_ctx* ctx) {
+    StuffParams tp;
+    tp.slots = ctx->slots.p;
+    tp.chunk_bits = ctx->chunk_bits.p;
+    tp.bit_off = ctx->bit_off.p;
+    tp.chunk_ff = ctx->chunk_ff.p;
+    tp.ff_off = ctx->ff_off.p;
+    tp.words_out = nullptr;
+    tp.out_stride = 0;
+    tp.cap_words = 0;
+    tp.results = nullptr;
+    tp.cpi = ctx->seg_cpi;
+    tp.pred_tail8 = ctx->seg_prev_tail8;
+    tp.bit_base = ctx->seg_bit_offset;
+    tp.ff_base = 0;
+    tp.out_word_base = 0;
+    tp.eof = 0;
+    return tp;
+}
+}  // namespace
+
+int jpegenc_segment_count(jpegenc_ctx* ctx, uint64_t bit_offset, uint32_t prev_tail8, uint64_t* ff_bytes) {
+    if (!ctx || !ff_bytes) return JPEGENC_E_BAD_ARG;
+    if (!ctx->seg_ready) return JPEGENC_E_STATE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->seg_bit_offset = bit_offset;
+    ctx->seg_prev_tail8 = prev_tail8 & 0xFFu;
+    StuffParams tp = segment_params(ctx);
+    HIPCHK(ctx, launch_stuff_count(tp, 1, ctx->stream));
+    ScanParams sp;
+    sp.counts = ctx->chunk_ff.p;
+    sp.prefix = ctx->ff_off.p;
+    sp.cpi = ctx->seg_cpi;
+    HIPCHK(ctx, launch_scan(sp, 1, ctx->stream));
+    uint32_t last_count = 0;
+    uint64_t last_off = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&last_count, ctx->chunk_ff.p + (ctx->seg_cpi - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&last_off, ctx->ff_off.p + (ctx->seg_cpi - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->seg_ff = last_off + last_count;
+    ctx->seg_counted = true;
+    *ff_bytes = ctx->seg_ff;
+    return JPEGENC_OK;
+}
+
+int jpegenc_segment_write(jpegenc_ctx* ctx, uint64_t ff_offset, int is_last, uint32_t flags, uint32_t* words_out,
+                          size_t cap_words, uint64_t* first_word, uint64_t* n_words, jpegenc_result* result) {
+    if (!ctx || !words_out || !first_word || !n_words || cap_words == 0) return JPEGENC_E_BAD_ARG;
+    if (is_last && !result) return JPEGENC_E_BAD_ARG;
+    if (!ctx->seg_ready || !ctx->seg_counted) return JPEGENC_E_STATE;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint64_t o = ctx->seg_bit_offset, end_bits = o + ctx->seg_bits;
+    const uint64_t pos0 = (o >> 3) + ff_offset;
+    const uint64_t end_pos = (end_bits >> 3) + ff_offset + ctx->seg_ff;  // stuffed bytes of the whole stream so far
+    const uint64_t fw = pos0 >> 2;
+    const uint64_t end_word = is_last ? ((end_pos * 8 + (end_bits & 7u) + 31u) >> 5) : ((end_pos + 3u) >> 2);
+    *first_word = fw;
+    *n_words = end_word - fw;
+    const size_t n_store = size_t(std::min<uint64_t>(*n_words, cap_words));
+    uint32_t* d_words = words_out;
+    if (!(flags & JPEGENC_DEVICE_PTRS)) {
+        HIPCHK(ctx, ctx->out_stage.reserve(cap_words));
+        d_words = ctx->out_stage.p;
+    }
+    HIPCHK(ctx, ctx->res_stage.reserve(1));
+    // bytes of boundary words that belong to the neighbouring segments stay zero: the caller ORs those words
+    HIPCHK(ctx, hipMemsetAsync(d_words, 0, n_store * 4, ctx->stream));
+    StuffParams tp = segment_params(ctx);
+    tp.words_out = d_words;
+    tp.cap_words = cap_words;
+    tp.results = ctx->res_stage.p;
+    tp.ff_base = ff_offset;
+    tp.out_word_base = fw;
+    tp.eof = is_last ? 1u : 0u;
+    HIPCHK(ctx, launch_stuff_write(tp, 1, ctx->stream));
+    if (is_last)
+        HIPCHK(ctx, hipMemcpyAsync(result, ctx->res_stage.p, sizeof(jpegenc_result), hipMemcpyDeviceToHost, ctx->stream));
+    if (!(flags & JPEGENC_DEVICE_PTRS) && n_store)
+        HIPCHK(ctx, hipMemcpyAsync(words_out, d_words, n_store * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->seg_ready = ctx->seg_counted = false;
+    return (*n_words > cap_words) ? JPEGENC_E_TOO_SMALL : JPEGENC_OK;
 }
 
 int jpegenc_reset(jpegenc_ctx* ctx) {

@@ -34,7 +34,8 @@ struct EncodeParams {
     uint32_t mcu_w;        // MCUs per block row (w / 8)
     uint32_t n_mcu;        // MCUs per image
     uint32_t cpi;          // chunks per image = ceil(n_mcu / 64)
-    uint32_t flags;        // bit 0: rgb wrap quirk, bit 1: cb 6'd64 quirk
+    uint32_t flags;        // bit 0: rgb wrap quirk, bit 1: cb 6'd64 quirk, bit 2: the images continue a
+                           // stream: the DC predictors of their first MCU come from the block row above
     uint32_t* slots;       // [n_images * cpi][kSlotWords]
     uint32_t* chunk_bits;  // [n_images * cpi]
     const uint32_t* htab;  // [kHtabEntries]
@@ -58,6 +59,14 @@ struct StuffParams {
     uint64_t cap_words;       // capacity per image
     jpegenc_result* results;  // first image of this launch (device memory)
     uint32_t cpi;
+    // A segment of a longer stream (all zero, eof = 1 for whole images): where the image's stream starts in
+    // the whole one, the 0xFF bytes before it, the word of the whole stream that words_out[0] stands for,
+    // the last 8 bits before the segment, and whether the image's end is the end of the file.
+    uint32_t pred_tail8;
+    uint64_t bit_base;
+    uint64_t ff_base;
+    uint64_t out_word_base;
+    uint32_t eof;
 };
 
 // Launchers (defined in jpegenc_kernels.hip).  align = 8, 4 or 1: guaranteed alignment of every

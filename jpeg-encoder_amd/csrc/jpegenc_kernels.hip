@@ -454,11 +454,17 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
     const uint8_t* src = img_base + (int64_t)by * 8 * p.stride + (int64_t)bx * 24;
 
     // DC predictors for lane 0: the MCU just before this chunk (0 at the start of an image: rst)
+    // (a segment that continues an image, flags bit 2, takes them from the last MCU of the block row above
+    // its first row)
     int halo[3] = {0, 0, 0};
-    if (c > 0) {
-        const uint32_t hb = c * kChunkMcus - 1;
-        const uint32_t hy = hb / p.mcu_w, hx = hb - hy * p.mcu_w;
-        const uint8_t* hp = img_base + ((int64_t)hy * 8 + (lane >> 3)) * p.stride + (int64_t)hx * 24 + (lane & 7) * 3;
+    if (c > 0 || (p.flags & 4u)) {
+        int64_t hy = -1, hx = (int64_t)p.mcu_w - 1;
+        if (c > 0) {
+            const uint32_t hb = c * kChunkMcus - 1;
+            hy = hb / p.mcu_w;
+            hx = hb - (uint32_t)hy * p.mcu_w;
+        }
+        const uint8_t* hp = img_base + (hy * 8 + (lane >> 3)) * p.stride + hx * 24 + (lane & 7) * 3;
         const uint32_t R = hp[0], G = hp[1], B = hp[2];
 #pragma unroll
         for (int comp = 0; comp < 3; ++comp) {
@@ -748,14 +754,14 @@ __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_count(StuffParams p,
     }
     const uint32_t c = gid % p.cpi;
     const uint32_t n = p.chunk_bits[gid] & kCountMask;
-    const uint64_t o = p.bit_off[gid];
+    const uint64_t o = p.bit_off[gid] + p.bit_base;
     const uint32_t sbits = (uint32_t)(o & 7u);  // bits of the first owned byte that lie in the predecessor
     const uint32_t A = (8u - sbits) & 7u;
     const uint32_t nbytes = (uint32_t)(((o + n) >> 3) - (o >> 3));
     const uint32_t nm = nbytes - (sbits ? 1u : 0u);  // owned bytes that lie entirely in this chunk
     uint32_t total = 0;
     if (sbits != 0 && lane == 0) {
-        const uint32_t pw = (c > 0) ? (p.chunk_bits[gid - 1] >> 24) : 0u;
+        const uint32_t pw = (c > 0) ? (p.chunk_bits[gid - 1] >> 24) : p.pred_tail8;
         const uint32_t sb = ((pw << A) | (readlane_u32(w[0].x, 0) >> (32u - A))) & 0xFFu;
         total = (sb == 0xFFu) ? 1u : 0u;
     }
@@ -822,7 +828,7 @@ __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_write(StuffParams p,
     const uint32_t img = gid / p.cpi;
     const uint32_t c = gid - img * p.cpi;
     const uint32_t n = p.chunk_bits[gid] & kCountMask;
-    const uint64_t o = p.bit_off[gid];
+    const uint64_t o = p.bit_off[gid] + p.bit_base;
     const uint64_t q_first = o >> 3;
     const uint32_t sbits = (uint32_t)(o & 7u);
     const uint32_t A = (8u - sbits) & 7u;
@@ -832,13 +838,13 @@ __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_write(StuffParams p,
     uint32_t* const out_words = p.words_out + (uint64_t)img * p.out_stride;
     uint8_t* const out_bytes = reinterpret_cast<uint8_t*>(out_words);
     const uint64_t cap_bytes = p.cap_words * 4;
-    const uint64_t pos0 = q_first + p.ff_off[gid];  // stuffed byte offset of the first owned byte
-    uint64_t wbase = pos0 >> 2;                     // global word index of stage[0]
+    const uint64_t pos0 = q_first + p.ff_off[gid] + p.ff_base;  // stuffed byte offset of the first owned byte
+    uint64_t wbase = (pos0 >> 2) - p.out_word_base;             // index in out_words of stage[0]
     uint32_t head = (uint32_t)(pos0 & 3u);          // leading bytes of the stage's first word that belong to the previous chunk
     uint32_t fill = head;                           // bytes in the stage (uniform)
 
     if (sbits != 0) {  // the byte that begins in the predecessor: its last 8 bits travel with its bit count
-        const uint32_t pw = (c > 0) ? (p.chunk_bits[gid - 1] >> 24) : 0u;
+        const uint32_t pw = (c > 0) ? (p.chunk_bits[gid - 1] >> 24) : p.pred_tail8;
         const uint32_t sb = ((pw << A) | (readlane_u32(w[0].x, 0) >> (32u - A))) & 0xFFu;
         if (lane == 0) {
             stage[fill] = (uint8_t)sb;
@@ -969,7 +975,7 @@ __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_write(StuffParams p,
         }
     }
 
-    const bool last = (c == p.cpi - 1);
+    const bool last = (c == p.cpi - 1) && p.eof;
     if (!last) {
         // bytes after the last whole word belong to a word shared with the next chunk
         if ((uint32_t)lane >= head && (uint32_t)lane < fill) {
@@ -981,7 +987,7 @@ __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_write(StuffParams p,
         // left-aligned in one more word with their count (ff_checker.sv:289-360, functional)
         const uint64_t total_bits = o + n;
         const uint32_t rem = (uint32_t)(total_bits & 7u);
-        const uint64_t stuffed_bytes = wbase * 4 + fill;
+        const uint64_t stuffed_bytes = (wbase + p.out_word_base) * 4 + fill;
         if (lane == 0) {
             uint32_t f = fill;
             if (rem) {
@@ -995,7 +1001,7 @@ __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_write(StuffParams p,
         }
         fill = (fill + (rem ? 1u : 0u) + 3u) & ~3u;
         wave_sync();
-        const uint32_t tail_idx = (uint32_t)(((stuffed_bytes * 8 + rem) >> 5) - wbase);  // word holding the residual
+        const uint32_t tail_idx = (uint32_t)(((stuffed_bytes * 8 + rem) >> 5) - p.out_word_base - wbase);  // word holding the residual
         const uint32_t tail_raw = (tail_idx * 4 < fill) ? reinterpret_cast<const uint32_t*>(stage)[tail_idx] : 0u;
         flush(true);
         if (lane == 0) {
@@ -1007,7 +1013,7 @@ __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_write(StuffParams p,
             r.tail_bits = (uint8_t)(sbits_total & 31u);
             r.eof_partial_ready = r.tail_bits ? 1 : 0;
             r.tail_word = r.tail_bits ? __builtin_bswap32(tail_raw) : 0u;
-            const uint64_t need = r.n_full_words + (r.tail_bits ? 1 : 0);
+            const uint64_t need = r.n_full_words + (r.tail_bits ? 1 : 0) - p.out_word_base;
             r.status = (need > p.cap_words) ? (int16_t)JPEGENC_E_TOO_SMALL : (int16_t)JPEGENC_OK;
             p.results[img] = r;
         }

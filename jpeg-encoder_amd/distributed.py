@@ -10,6 +10,11 @@ image encoded after `rst` is exactly a restart interval.
 * one huge image   -> stripe s goes to rank s % world; the only exchange step is the reassembly of the
   variable-length stripe streams on the root: one all_gather of the stripe tables (a few words per
   stripe) and one grouped send/recv of the payloads (`gather_stripes`).
+* one huge image, one stream -> band r (whole block rows) goes to rank r; the bands are coupled by what
+  the RTL carries from block to block -- DC predictors (cr_huff.sv:591-596: read from the 8 pixel rows
+  above the band), running bit offset (fifo_out.sv:222-243) and stuffed byte count
+  (ff_checker.sv:96-179) -- so two tiny all_gathers (bit counts, then 0xFF counts) sit between the three
+  phases of the band coder, and the root ORs the bands' words together (`encode_monolithic`).
 """
 import numpy as np
 
@@ -86,3 +91,77 @@ def encode_striped_image(encode_stripe, n_stripes, device=None, root=0, group=No
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     local = {s: encode_stripe(s) for s in stripes_of_rank(n_stripes, rank, world)}
     return gather_stripes(local, n_stripes, device=device, root=root, group=group)
+
+
+def band_rows(h, rank, world):
+    """Rows [lo, hi) of band `rank` when an image of h rows (a multiple of 8) is cut into `world` bands of
+    whole block rows."""
+    lo, hi = shard_range(h // 8, rank, world)
+    return 8 * lo, 8 * hi
+
+
+def encode_monolithic(band, device=None, root=0, group=None):
+    """One stream for one image from one band per rank (band r directly above band r + 1).
+
+    `band` is this rank's band coder, an object with the three phases of the C ABI's segment calls:
+        band.encode() -> (bits, tail8)
+        band.count(bit_offset, prev_tail8) -> ff_bytes
+        band.write(ff_offset, is_last) -> (first_word, words, result or None)
+    with `words` a 1-D uint32 numpy array (or torch tensor of int32 bit patterns on `device`).
+    Returns on root (words, result): the words of jpeg_top's single run over the whole image and the
+    result record of the last band (a mapping/record with the jpegenc_result fields); elsewhere
+    (None, None)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = device if device is not None else torch.device("cpu")
+
+    def gather_row(values):
+        mine = torch.tensor(values, dtype=torch.int64, device=dev)
+        rows = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(rows, mine, group=group)
+        return torch.stack(rows).cpu().numpy()
+
+    bits, tail8 = band.encode()
+    t = gather_row([bits, tail8])
+    bit_offset = int(t[:rank, 0].sum())
+    prev_tail = int(t[rank - 1, 1]) if rank else 0
+    ff = band.count(bit_offset, prev_tail)
+    f = gather_row([ff])
+    first_word, words, result = band.write(int(f[:rank, 0].sum()), rank == world - 1)
+    if not torch.is_tensor(words):
+        words = torch.from_numpy(np.ascontiguousarray(words).view(np.int32))
+    words = words.view(torch.int32).to(dev)
+    res_row = [0] * 7
+    if result is not None:
+        res_row = [int(result[k]) for k in ("n_full_words", "total_bits_unstuffed", "total_bytes_stuffed", "tail_word",
+                                            "tail_bits", "eof_partial_ready", "status")]
+    spans = gather_row([first_word, int(words.numel())] + res_row)
+    total = int((spans[:, 0] + spans[:, 1]).max())
+    ops, parts = [], {}
+    if rank == root:
+        for r in range(world):
+            if r == root:
+                parts[r] = words
+            else:
+                parts[r] = torch.zeros(int(spans[r, 1]), dtype=torch.int32, device=dev)
+                if parts[r].numel():
+                    ops.append(dist.P2POp(dist.irecv, parts[r], r, group=group, tag=r))
+    elif words.numel():
+        ops.append(dist.P2POp(dist.isend, words.contiguous(), root, group=group, tag=rank))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    if rank != root:
+        return None, None
+    out = torch.zeros(total, dtype=torch.int32, device=dev)
+    for r in range(world):  # neighbouring bands share their boundary words: each wrote only its own bytes
+        a = int(spans[r, 0])
+        out[a:a + parts[r].numel()] |= parts[r]
+    last = spans[world - 1]
+    if int(last[6]):  # the tail word may be shared with the band before the last: take it from the merged words
+        last[5] = int(out[int(last[2])].item()) & 0xFFFFFFFF
+    result = dict(n_full_words=int(last[2]), total_bits_unstuffed=int(last[3]), total_bytes_stuffed=int(last[4]),
+                  tail_word=int(last[5]), tail_bits=int(last[6]), eof_partial_ready=int(last[7]), status=int(last[8]))
+    return out, result

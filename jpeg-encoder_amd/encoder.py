@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libjpegenc.so")
 
 OK, E_BAD_ARG, E_TOO_SMALL, E_HIP, E_UNSUPPORTED, E_NOMEM, E_STATE = 0, -1, -2, -3, -4, -5, -6
 HOST_PTRS, DEVICE_PTRS = 0, 1
+SEG_CONTINUES = 2
 N_KERNELS = 4
 
 # every symbol include/jpegenc.h declares
@@ -25,7 +26,8 @@ ABI_SYMBOLS = [
     "jpegenc_max_words", "jpegenc_encode_rgb8", "jpegenc_encode_batch", "jpegenc_encode_stripes", "jpegenc_reset",
     "jpegenc_push_pixel", "jpegenc_push_pixels", "jpegenc_end_of_file", "jpegenc_read_words",
     "jpegenc_words_to_bytes", "jpegenc_set_profiling", "jpegenc_kernel_times", "jpegenc_kernel_name",
-    "jpegenc_set_workspace_limit", "jpegenc_strerror", "jpegenc_last_error", "jpegenc_version",
+    "jpegenc_set_workspace_limit", "jpegenc_segment_encode", "jpegenc_segment_count",
+    "jpegenc_segment_write", "jpegenc_strerror", "jpegenc_last_error", "jpegenc_version",
 ]
 
 
@@ -92,6 +94,10 @@ def load_library(path=None):
     L.jpegenc_kernel_name.argtypes = [i32]
     L.jpegenc_kernel_name.restype = C.c_char_p
     L.jpegenc_set_workspace_limit.argtypes = [vp, sz]
+    u64 = C.c_uint64
+    L.jpegenc_segment_encode.argtypes = [vp, vp, i32, i32, C.c_ssize_t, u32, C.POINTER(u64), C.POINTER(u32)]
+    L.jpegenc_segment_count.argtypes = [vp, u64, u32, C.POINTER(u64)]
+    L.jpegenc_segment_write.argtypes = [vp, u64, i32, u32, vp, sz, C.POINTER(u64), C.POINTER(u64), C.POINTER(Result)]
     L.jpegenc_strerror.argtypes = [i32]
     L.jpegenc_strerror.restype = C.c_char_p
     L.jpegenc_last_error.argtypes = [vp]
@@ -209,6 +215,50 @@ class JpegTop:
                                                   C.c_void_p(results_ptr)))
 
     # -- port-level protocol -----------------------------------------------------------------
+    # -- one stream from consecutive bands of an image -----------------------------------------
+    def segment_encode(self, image, row0, rows):
+        """Codes rows [row0, row0 + rows) of the (h, w, 3) uint8 host array `image` as a band of the
+        image's single stream.  Returns (bits, tail8)."""
+        assert image.dtype == np.uint8 and image.ndim == 3 and image.shape[2] == 3 and image.flags.c_contiguous
+        h, w, _ = image.shape
+        assert 0 <= row0 and row0 + rows <= h and row0 % 8 == 0
+        bits, tail = C.c_uint64(), C.c_uint32()
+        ptr = image.ctypes.data + row0 * w * 3
+        self._check(self.lib.jpegenc_segment_encode(self._ctx, ptr, w, rows, w * 3,
+                                                    HOST_PTRS | (SEG_CONTINUES if row0 else 0),
+                                                    C.byref(bits), C.byref(tail)))
+        return int(bits.value), int(tail.value)
+
+    def segment_encode_device(self, rgb_ptr, w, rows, stride, continues):
+        """Same with a device pointer to the band's first row (the 8 rows above it must be readable when
+        `continues`)."""
+        bits, tail = C.c_uint64(), C.c_uint32()
+        self._check(self.lib.jpegenc_segment_encode(self._ctx, C.c_void_p(rgb_ptr), w, rows, stride,
+                                                    DEVICE_PTRS | (SEG_CONTINUES if continues else 0),
+                                                    C.byref(bits), C.byref(tail)))
+        return int(bits.value), int(tail.value)
+
+    def segment_count(self, bit_offset, prev_tail8):
+        ff = C.c_uint64()
+        self._check(self.lib.jpegenc_segment_count(self._ctx, int(bit_offset), int(prev_tail8), C.byref(ff)))
+        return int(ff.value)
+
+    def segment_write(self, ff_offset, is_last, cap_words):
+        """Returns (first_word, words, result or None): words[i] is word first_word + i of the whole
+        stream; bytes of its first and last word that belong to the neighbouring bands are zero."""
+        words = np.zeros(cap_words, dtype=np.uint32)
+        res = Result()
+        fw, nw = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.jpegenc_segment_write(self._ctx, int(ff_offset), int(bool(is_last)), HOST_PTRS,
+                                                   words.ctypes.data, cap_words, C.byref(fw), C.byref(nw),
+                                                   C.byref(res)))
+        rec = None
+        if is_last:
+            rec = np.zeros(1, dtype=RESULT_DTYPE)
+            C.memmove(rec.ctypes.data, C.byref(res), 32)
+            rec = rec[0]
+        return int(fw.value), words[:int(nw.value)], rec
+
     def reset(self):
         self._check(self.lib.jpegenc_reset(self._ctx))
 

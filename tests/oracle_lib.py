@@ -113,3 +113,70 @@ def huff_block(blk_huff_order, comp, pred=0, cfg=None):
     n = lib().ref_huff_block(C.byref(cfg), comp, blk.ctypes.data, C.byref(p), bits.ctypes.data, bits.size)
     assert n >= 0
     return "".join(str(int(b)) for b in bits[:n]), p.value
+
+
+def unstuffed_bits(rgb, cfg=None):
+    """The image's Huffman bit stream before stuffing, as a uint8 array of 0/1."""
+    cfg = cfg or default_config()
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w, _ = rgb.shape
+    cap = lib().ref_max_words(w, h) * 4
+    buf = np.zeros(cap, dtype=np.uint8)
+    nbits = C.c_uint64()
+    rc = lib().ref_encode_rgb8_unstuffed(C.byref(cfg), rgb.ctypes.data, w, h, w * 3, buf.ctypes.data, cap,
+                                         C.byref(nbits))
+    if rc:
+        raise RuntimeError("ref_encode_rgb8_unstuffed rc=%d" % rc)
+    return np.unpackbits(buf)[:nbits.value]
+
+
+class OracleBand:
+    """CPU stand-in for the three segment calls of the C ABI on rows [lo, hi) of `image`, built on the
+    oracle: the stream of the first k MCUs is a prefix of the whole image's stream, so a band's bits are
+    the difference of two prefix encodings."""
+
+    def __init__(self, image, lo, hi, cfg=None):
+        full = unstuffed_bits(image[:hi], cfg)
+        skip = len(unstuffed_bits(image[:lo], cfg)) if lo else 0
+        self.bits = full[skip:]
+
+    def encode(self):
+        return len(self.bits), int(np.packbits(self.bits[-8:])[0])
+
+    def _owned(self):
+        s = self.o & 7
+        pre = np.unpackbits(np.array([self.prev], dtype=np.uint8))[8 - s:] if s else np.zeros(0, np.uint8)
+        allbits = np.concatenate([pre, self.bits])
+        nbytes = ((self.o + len(self.bits)) >> 3) - (self.o >> 3)
+        return np.packbits(allbits[:8 * nbytes]), allbits[8 * nbytes:]
+
+    def count(self, bit_offset, prev_tail8):
+        self.o, self.prev = bit_offset, prev_tail8
+        return int((self._owned()[0] == 0xFF).sum())
+
+    def write(self, ff_offset, is_last):
+        owned, rest = self._owned()
+        out = []
+        for b in owned:
+            out.append(int(b))
+            if b == 0xFF:
+                out.append(0)
+        pos0 = (self.o >> 3) + ff_offset
+        first_word = pos0 >> 2
+        result = None
+        if is_last:
+            stuffed = pos0 + len(out)
+            rem = len(rest)
+            if rem:
+                out.append(int(np.packbits(np.concatenate([rest, np.zeros(8 - rem, np.uint8)]))[0]))
+            sbits = stuffed * 8 + rem
+            result = dict(n_full_words=sbits >> 5, total_bits_unstuffed=self.o + len(self.bits),
+                          total_bytes_stuffed=stuffed, tail_bits=sbits & 31, eof_partial_ready=int(sbits & 31 != 0),
+                          status=0)
+        lead = pos0 - 4 * first_word
+        raw = bytes(lead) + bytes(out)
+        raw += bytes((-len(raw)) % 4)
+        words = np.frombuffer(raw, dtype=">u4").astype(np.uint32)
+        if is_last:
+            result["tail_word"] = int(words[result["n_full_words"] - first_word]) if result["tail_bits"] else 0
+        return first_word, words, result

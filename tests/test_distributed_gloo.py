@@ -45,6 +45,18 @@ def worker(rank, world, port, mode, out_dir):
                 np.save(os.path.join(out_dir, "payload.npy"), payload.numpy().view(np.uint32))
             else:
                 assert table is None and payload is None
+        elif mode == "mono":
+            # one stream from one band per rank; the band coder is the oracle stand-in
+            for k, img in enumerate(mono_images()):
+                lo, hi = pkg.distributed.band_rows(img.shape[0], rank, world)
+                words, res = pkg.distributed.encode_monolithic(O.OracleBand(img, lo, hi))
+                if rank == 0:
+                    np.save(os.path.join(out_dir, "mono%d.npy" % k), words.numpy().view(np.uint32))
+                    np.save(os.path.join(out_dir, "mono%d_res.npy" % k),
+                            np.array([res["n_full_words"], res["tail_bits"], res["tail_word"],
+                                      res["total_bits_unstuffed"], res["total_bytes_stuffed"]], dtype=np.int64))
+                else:
+                    assert words is None and res is None
         else:
             # batch sharding: every rank encodes its contiguous range; rank 0 checks the ranges tile the batch
             n = 7
@@ -59,6 +71,11 @@ def worker(rank, world, port, mode, out_dir):
                 np.save(os.path.join(out_dir, "sizes.npy"), sizes.numpy())
     finally:
         dist.destroy_process_group()
+
+
+def mono_images():
+    return [natural_like(96, 72, 5), np.random.default_rng(8).integers(0, 256, (80, 64, 3), dtype=np.uint8),
+            np.full((16, 8, 3), 255, np.uint8)]
 
 
 def run(mode, tmp_path):
@@ -103,3 +120,35 @@ def test_batch_sharding_two_ranks(tmp_path):
     for i in range(7):
         img = np.random.default_rng(50 + i).integers(0, 256, (16, 24, 3), dtype=np.uint8)
         assert sizes[i] == len(O.encode(img)[0])
+
+
+def test_monolithic_stream_from_two_bands(tmp_path):
+    """Two ranks, one band each: the ORed words are the whole image's single stream."""
+    import oracle_lib as O
+    run("mono", tmp_path)
+    for k, img in enumerate(mono_images()):
+        want, r = O.encode(img)
+        got = np.load(tmp_path / ("mono%d.npy" % k))
+        res = np.load(tmp_path / ("mono%d_res.npy" % k))
+        assert np.array_equal(got, want)
+        assert tuple(res) == (r.n_full_words, r.tail_bits, r.tail_word, r.total_bits_unstuffed, r.total_bytes_stuffed)
+
+
+def test_oracle_band_stand_in_any_cut():
+    """The stand-in itself, without ranks: every cut of a small image into bands reproduces the stream."""
+    import oracle_lib as O
+    img = np.random.default_rng(12).integers(0, 256, (40, 24, 3), dtype=np.uint8)
+    img[8:16] = 255  # long runs of one-bits around a cut
+    want, r = O.encode(img)
+    for cuts in ([0, 40], [0, 8, 40], [0, 16, 24, 40], [0, 8, 16, 24, 32, 40]):
+        bands = [O.OracleBand(img, a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+        info = [b.encode() for b in bands]
+        offs = np.concatenate([[0], np.cumsum([i[0] for i in info])])
+        ffs = [b.count(int(offs[i]), info[i - 1][1] if i else 0) for i, b in enumerate(bands)]
+        ffo = np.concatenate([[0], np.cumsum(ffs)])
+        out = np.zeros(len(want) + 2, dtype=np.uint32)
+        for i, b in enumerate(bands):
+            fw, words, res = b.write(int(ffo[i]), i == len(bands) - 1)
+            out[fw:fw + len(words)] |= words
+        assert np.array_equal(out[:len(want)], want)
+        assert (res["n_full_words"], res["tail_bits"]) == (r.n_full_words, r.tail_bits)

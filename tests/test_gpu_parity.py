@@ -162,6 +162,58 @@ def test_batch_and_stripes(enc):
         assert_same(words[s], res[s], big[32 * s:32 * (s + 1)])
 
 
+def merged_bands(pkg, img, cuts, device_ptrs=False):
+    """Runs the three segment calls for every band (one context per band, as one GPU per band would) and
+    ORs the bands' words."""
+    bands = [pkg.JpegTop() for _ in cuts[:-1]]
+    try:
+        h, w, _ = img.shape
+        if device_ptrs:
+            import torch
+            d_img = torch.from_numpy(img).to("cuda:0")
+            torch.cuda.synchronize()
+            info = [e.segment_encode_device(d_img.data_ptr() + a * w * 3, w, b - a, w * 3, a > 0)
+                    for e, a, b in zip(bands, cuts[:-1], cuts[1:])]
+        else:
+            info = [e.segment_encode(img, a, b - a) for e, a, b in zip(bands, cuts[:-1], cuts[1:])]
+        offs = np.concatenate([[0], np.cumsum([i[0] for i in info])])
+        ffs = [e.segment_count(int(offs[i]), info[i - 1][1] if i else 0) for i, e in enumerate(bands)]
+        ffo = np.concatenate([[0], np.cumsum(ffs)])
+        out = np.zeros(pkg.max_words(w, h), dtype=np.uint32)
+        res = None
+        for i, (e, a, b) in enumerate(zip(bands, cuts[:-1], cuts[1:])):
+            fw, words, res = e.segment_write(int(ffo[i]), i == len(bands) - 1, pkg.max_words(w, b - a) + 2)
+            out[fw:fw + len(words)] |= words
+        return out, res, int(offs[-1]), int(ffo[-1])
+    finally:
+        for e in bands:
+            e.close()
+
+
+def test_bands_give_the_whole_images_stream(enc):
+    """One stream from consecutive bands (what several GPUs do for one huge image): DC predictors from the
+    block row above, global bit phase and 0xFF count handed from band to band."""
+    pkg = load_pkg()
+    rng = np.random.default_rng(44)
+    noise = rng.integers(0, 256, (136, 200, 3), dtype=np.uint8)
+    ones = np.full((48, 64, 3), 255, np.uint8)          # all-ones bytes straddle every cut
+    ones[16:24, 8:40] = rng.integers(0, 256, (8, 32, 3), dtype=np.uint8)
+    cases = [(natural_like(200, 328, 61), [0, 64, 72, 200]), (natural_like(200, 328, 62), [0, 200]),
+             (noise, [0, 8, 16, 24, 136]), (noise, [0, 72, 136]), (ones, [0, 8, 16, 24, 32, 40, 48]),
+             (natural_like(1080, 1920, 63), [0, 136, 544, 1080])]
+    for k, (img, cuts) in enumerate(cases):
+        want, r = O.encode(img)
+        got, res, bits, ff = merged_bands(pkg, img, cuts, device_ptrs=(k % 2 == 1))
+        assert bits == r.total_bits_unstuffed
+        assert int(res["n_full_words"]) == r.n_full_words and int(res["tail_bits"]) == r.tail_bits
+        assert int(res["total_bytes_stuffed"]) == r.total_bytes_stuffed and int(res["status"]) == 0
+        assert np.array_equal(got[:len(want)], want), "case %d" % k
+        assert not got[len(want):].any()
+        # and the single-context path gives the same words
+        words, _ = enc.encode(img)
+        assert np.array_equal(words, want)
+
+
 def test_output_too_small_is_reported_not_overrun(enc):
     pkg = load_pkg()
     rgb = np.random.default_rng(5).integers(0, 256, (64, 64, 3), dtype=np.uint8)
