@@ -37,7 +37,7 @@ void build_htab(uint32_t out[kHtabEntries]) {
     for (int s = 0; s < 12; ++s) {
         const uint32_t code = JPEGENC_DC_CODE[s];
         const uint32_t len = JPEGENC_DC_LEN[s];
-        out[kHtabDc + s] = ((len + s) << 27) | (code << s);
+        out[(s << 5) | kHtabDcSize] = ((len + s) << 27) | (code << s);
     }
 }
 

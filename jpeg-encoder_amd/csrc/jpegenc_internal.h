@@ -16,16 +16,18 @@ constexpr int kMaxMcuWords = 156;
 // Chunk stream slot in the workspace, in 32-bit words: worst case of 64 MCUs.
 constexpr int kSlotWords = kChunkMcus * kMaxMcuWords;  // 9984 words = 39,936 B
 
-// Packed Huffman table in LDS: entry = (total_length << 27) | (code << size), total_length = code length
-// + amplitude bits; 0 = nothing to emit.
-//   [0, 512)   AC, index = run << 5 | eob << 4 | size.  (run <= 14, size 0) is a zero coefficient inside
-//              a run: nothing; (run 15, size 0) is the 16th zero: ZRL in the eob = 0 entries, nothing in the
-//              eob = 1 entries (rtl/4_huffman/cr_huff.sv:558).
-//   [512]      EOB
-//   [528, 540) DC by size
-constexpr int kHtabEntries = 544;
-constexpr int kHtabEob = 512;
-constexpr int kHtabDc = 528;
+// Huffman table, one 32-bit word per entry in global memory: (total_length << 27) | (code << size) with
+// total_length = code length + amplitude bits, 0 = nothing to emit.  The kernel keeps the two fields in
+// two LDS arrays (a word and a byte per entry), so a lookup needs no unpacking.
+// Index = run << 5 | eob << 4 | size:
+//   size 0..10  AC.  (run <= 14, size 0) is a zero coefficient inside a run: nothing; (run 15, size 0) is
+//               the 16th zero: ZRL in the eob = 0 entries, nothing in the eob = 1 entries
+//               (rtl/4_huffman/cr_huff.sv:558).
+//   size 14, run 0, eob 0   the EOB code (an AC size never exceeds 10, so sizes 11..15 are free)
+//   size 15, eob 0          the DC code of size `run` (0..11)
+constexpr int kHtabEntries = 512;
+constexpr int kHtabEob = 14;
+constexpr int kHtabDcSize = 15;
 
 struct EncodeParams {
     const uint8_t* rgb;    // first image of this launch

@@ -273,7 +273,14 @@ __device__ __forceinline__ void bw_emit(BitWriter& s, uint32_t bits, uint32_t le
 // run, size and the end_of_block flag, and empty entries make a zero coefficient emit nothing.
 // t = v for v >= 0, v - 1 for v < 0: its low `size` bits are the amplitude, and the number of leading
 // bits equal to its sign bit is 32 - size (v = -4: t = ...11011, 29 leading ones, size 3).
-__device__ __forceinline__ int amp_src(int v) { return v + (v >> 31); }
+// One instruction: the second operand is byte 3 of v, sign-extended (0 or -1 for the 11/12-bit values here).
+__device__ __forceinline__ int amp_src(int v) {
+    int t;
+    asm("v_add_u32_sdwa %0, %1, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3"
+        : "=v"(t)
+        : "v"(v));
+    return t;
+}
 // v_ffbh_i32: number of leading bits equal to the sign bit, -1 when all 32 are (t = 0; t = -1 cannot
 // occur since v = 0 maps to t = 0).
 __device__ __forceinline__ int lead_bits(int t) {
@@ -288,12 +295,13 @@ __device__ __forceinline__ uint32_t amp_bits(int t, uint32_t size) {
 
 template <bool GUARD>
 __device__ __forceinline__ void encode_block(const int (&blk)[64], int dc_pred, bool cb_eob_quirk,
-                                             const uint32_t* htab, uint32_t* priv, BitWriter& bw) {
+                                             const uint32_t* htab, const uint8_t* hlen, uint32_t* priv,
+                                             BitWriter& bw) {
     {   // DC difference, 12 bit (cr_huff.sv:1317): |d| <= 2047 for 11-bit inputs, no wrap possible
         const int t = amp_src(blk[0] - dc_pred);
         const uint32_t size = mag_bits(lead_bits(t));
-        const uint32_t ent = htab[kHtabDc + size];
-        bw_emit<GUARD>(bw, (ent & 0x7FFFFFFu) | amp_bits(t, size), ent >> 27, priv);
+        const uint32_t at = ((uint32_t)size << 5) | kHtabDcSize;
+        bw_emit<GUARD>(bw, htab[at] | amp_bits(t, size), hlen[at], priv);
     }
     // group-of-eight all-zero tests over zig-zag indices 16..63 (cr_huff.sv:190-204)
     int o2 = 0, o3 = 0, o4 = 0, o5 = 0, o6 = 0, o7 = 0;
@@ -324,8 +332,8 @@ __device__ __forceinline__ void encode_block(const int (&blk)[64], int dc_pred, 
         const uint32_t size = mag_bits(lead);
         // a run of 15 zeros cannot complete before k = 16, so the flag only matters from there on
         const uint32_t eob = (k < 16) ? 0u : (k + 2 < 32) ? eob_a : (k + 2 < 48) ? eob_b : eob_c;
-        const uint32_t ent = htab[r5 | size | eob];
-        bw_emit<GUARD>(bw, (ent & 0x7FFFFFFu) | amp_bits(t, size), ent >> 27, priv);
+        const uint32_t at = r5 | size | eob;
+        bw_emit<GUARD>(bw, htab[at] | amp_bits(t, size), hlen[at], priv);
         // zero coefficient (lead == -1, all ones): run + 1 modulo 16; otherwise the run restarts (lead is
         // at most 31 then and has no bit in common with the run field)
         r5 = (r5 + 32u) & (uint32_t)lead & 0x1E0u;
@@ -334,8 +342,8 @@ __device__ __forceinline__ void encode_block(const int (&blk)[64], int dc_pred, 
         const int v = blk[63];
         const int t = amp_src(v);
         const uint32_t size = mag_bits(lead_bits(t));
-        const uint32_t ent = htab[(v != 0) ? (r5 | size) : (uint32_t)kHtabEob];
-        bw_emit<GUARD>(bw, (ent & 0x7FFFFFFu) | amp_bits(t, size), ent >> 27, priv);
+        const uint32_t at = (v != 0) ? (r5 | size) : (uint32_t)kHtabEob;
+        bw_emit<GUARD>(bw, htab[at] | amp_bits(t, size), hlen[at], priv);
     }
 }
 
@@ -436,14 +444,19 @@ static_assert(4 * kRegionWords - 2 >= kMaxMcuWords, "tier 3 must hold the worst-
 template <int ALIGN, bool QUANT, bool WRAP>
 __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
     __shared__ uint32_t priv[kPrivWords];
-    __shared__ uint32_t htab[kHtabEntries];
+    __shared__ uint32_t htab[kHtabEntries];  // code << size
+    __shared__ uint8_t hlen[kHtabEntries];   // code length + size
     const int lane = threadIdx.x;
     const uint32_t gid = blockIdx.x;
     const uint32_t img = gid / p.cpi;
     const uint32_t c = gid - img * p.cpi;
     const bool cb_quirk = (p.flags & 2u) != 0;
 
-    for (int i = lane; i < kHtabEntries; i += 64) htab[i] = p.htab[i];
+    for (int i = lane; i < kHtabEntries; i += 64) {
+        const uint32_t e = p.htab[i];
+        htab[i] = e & 0x7FFFFFFu;
+        hlen[i] = (uint8_t)(e >> 27);
+    }
 
     const uint32_t b = c * kChunkMcus + lane;
     const bool valid = b < p.n_mcu;
@@ -551,9 +564,9 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
             const int h = (comp == 0) ? halo[0] : (comp == 1) ? halo[1] : halo[2];
             if (lane == 0) pred = h;
             if (n_groups == 1)
-                encode_block<false>(x, pred, comp == 1 && cb_quirk, htab, priv, bw);
+                encode_block<false>(x, pred, comp == 1 && cb_quirk, htab, hlen, priv, bw);
             else
-                encode_block<true>(x, pred, comp == 1 && cb_quirk, htab, priv, bw);
+                encode_block<true>(x, pred, comp == 1 && cb_quirk, htab, hlen, priv, bw);
         }
         // Every lane counts its bits whether or not it may store them, so the first pass already knows
         // which tier the chunk needs.
