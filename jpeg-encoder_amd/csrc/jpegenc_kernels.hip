@@ -1016,6 +1016,23 @@ __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_write(StuffParams p,
         const uint32_t rem = (uint32_t)(total_bits & 7u);
         const uint64_t stuffed_bytes = (wbase + p.out_word_base) * 4 + fill;
         if (lane == 0) {
+            if (head != 0 && c > 0) {
+                // Nothing has left the stage yet and its first word is shared with the previous chunk, so
+                // the word reported as tail_word may be that one: fetch the previous chunk's last `head`
+                // stuffed bytes (its last three owned bytes with their stuffing suffice) into the stage.
+                // They are only read here; in memory that chunk writes them itself.
+                const uint32_t np = p.chunk_bits[gid - 1] & kCountMask;
+                const uint32_t* Sp = S - kSlotWords;
+                const uint32_t l = np - sbits - 24u, wi = l >> 5, sh = l & 31u;
+                const uint32_t w32 = sh ? __builtin_amdgcn_alignbit(Sp[wi], Sp[wi + 1], 32u - sh) : Sp[wi];
+                uint32_t seq = 0;  // the last stuffed bytes, newest in the low byte
+                for (int k = 2; k >= 0; --k) {
+                    const uint32_t b = (w32 >> (8 + 8 * k)) & 0xFFu;
+                    seq = (seq << 8) | b;
+                    if (b == 0xFFu) seq <<= 8;
+                }
+                for (uint32_t k = 0; k < head; ++k) stage[k] = (uint8_t)(seq >> (8 * (head - 1 - k)));
+            }
             uint32_t f = fill;
             if (rem) {
                 // the last rem bits of the chunk stream, left-aligned in a byte

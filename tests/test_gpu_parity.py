@@ -85,6 +85,20 @@ def test_ragged_sizes_random(enc, hw):
     assert_same(words, res, rgb)
 
 
+def test_tiny_last_chunk_shares_its_word(enc):
+    """65 MCUs = one full chunk and one of a single flat MCU (18 bits): the image's last word, the one
+    reported as tail_word, then mostly belongs to the first chunk (found by tools/fuzz_gpu.py)."""
+    for seed in (14, 18, 19, 29, 32, 35, 0, 1):  # the first six put the last chunk's bytes into the shared word
+        rgb = np.random.default_rng(700 + seed).integers(0, 256, (8, 520, 3), dtype=np.uint8)
+        rgb[:, 504:] = rgb[0, 504]  # the last two MCUs flat and equal: zero DC differences in the last one
+        words, res = enc.encode(rgb)
+        assert_same(words, res, rgb)
+    big = np.kron(np.random.default_rng(3).integers(0, 2, (33, 33, 3)) * 255, np.ones((8, 8, 1))).astype(np.uint8)
+    words, res = enc.encode_batch(np.stack([big, big[::-1].copy()]))
+    for i, img in enumerate((big, big[::-1])):
+        assert_same(words[i], res[i], np.ascontiguousarray(img))
+
+
 def test_natural_and_noise_1080p(enc):
     rgb = natural_like(1080, 1920, 2)
     words, res = enc.encode(rgb)
