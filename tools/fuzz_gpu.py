@@ -43,7 +43,11 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
     t0, n, px = time.time(), 0, 0
+    last = t0
     while time.time() - t0 < budget:
+        if time.time() - last > 20:
+            last = time.time()
+            print("  ... %d images, %.0f s" % (n, last - t0), flush=True)
         kw = {}
         if rng.random() < 0.4:
             kw["qtabs"] = [rng.integers(1, int(rng.integers(2, 256)), 64) for _ in range(3)]
@@ -53,9 +57,44 @@ def main():
         with pkg.JpegTop(**kw) as e:
             for _ in range(4):
                 h, w = 8 * int(rng.integers(1, 40)), 8 * int(rng.integers(1, 70))
-                nimg = int(rng.integers(1, 4))
-                imgs = np.stack([image(rng, h, w) for _ in range(nimg)])
-                words, res = e.encode_batch(imgs)
+                mode = rng.integers(0, 4)
+                if mode == 3 and h >= 16:  # one stream from bands (fresh contexts, same configuration)
+                    img = image(rng, h, w)
+                    cuts = sorted(set([0, h] + [8 * int(c) for c in rng.integers(1, h // 8, int(rng.integers(1, 4)))]))
+                    bands = [pkg.JpegTop(**kw) for _ in cuts[:-1]]
+                    info = [b.segment_encode(img, a, c - a) for b, a, c in zip(bands, cuts[:-1], cuts[1:])]
+                    offs = np.concatenate([[0], np.cumsum([i[0] for i in info])])
+                    ffs = [b.segment_count(int(offs[i]), info[i - 1][1] if i else 0) for i, b in enumerate(bands)]
+                    ffo = np.concatenate([[0], np.cumsum(ffs)])
+                    out = np.zeros(pkg.max_words(w, h), dtype=np.uint32)
+                    for i, (b, a, c) in enumerate(zip(bands, cuts[:-1], cuts[1:])):
+                        fw, ww, rr = b.segment_write(int(ffo[i]), i == len(bands) - 1, pkg.max_words(w, c - a) + 2)
+                        out[fw:fw + len(ww)] |= ww
+                        b.close()
+                    want, r = O.encode(img, cfg)
+                    if not (np.array_equal(out[:len(want)], want) and not out[len(want):].any()
+                            and int(rr["n_full_words"]) == r.n_full_words and int(rr["tail_bits"]) == r.tail_bits):
+                        np.save("gpurun_out/fuzz_fail.npy", img)
+                        print("BAND MISMATCH", h, w, cuts, kw)
+                        sys.exit(1)
+                    n += 1
+                    px += h * w
+                    continue
+                if mode == 2 and h >= 16:  # stripes of one image
+                    img = image(rng, h, w)
+                    divs = [d for d in range(1, h // 8 + 1) if (h // 8) % d == 0]
+                    ns = int(rng.choice(divs))
+                    words, res = e.encode_stripes(img, ns)
+                    rows = h // ns
+                    imgs = np.stack([img[rows * k:rows * (k + 1)] for k in range(ns)])
+                    nimg = ns
+                    h = rows
+                else:
+                    nimg = int(rng.integers(1, 4))
+                    imgs = None
+                if imgs is None:
+                    imgs = np.stack([image(rng, h, w) for _ in range(nimg)])
+                    words, res = e.encode_batch(imgs)
                 for i in range(nimg):
                     want, r = O.encode(imgs[i], cfg)
                     ok = (len(words[i]) == len(want) and np.array_equal(words[i], want)
