@@ -73,7 +73,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
 
 // Three-input logic in one v_bitop3_b32 with register operands only.  On gfx950 this instruction, like
 // add/sub, and/or/xor, right shifts and moves, issues at twice the rate of v_or3_b32, v_and_or_b32,
-// left shifts, multiplies and anything with a scalar-register operand (measured, tools/micro/valu_cost.hip),
+// left shifts, multiplies and anything with a scalar-register operand (measured with tools/micro/valu_cost.hip),
 // and the compiler does not know the difference.
 __device__ __forceinline__ uint32_t or3_fast(uint32_t a, uint32_t b, uint32_t c) {
     uint32_t r;

@@ -1,7 +1,7 @@
 // Issue cost of the vector instructions the kernels are made of: a loop of 64 independent instances per
 // iteration (8 accumulators x 8), timed with s_memtime, one workgroup of 4, 8, 12 or 16 waves per CU (1 to 4
 // waves per SIMD).  Prints shader cycles per wave-instruction per SIMD (4.0 = 16 lanes/clock, 2.0 = 32).
-// Result on MI355X (profiles/r01_valu_issue_cost.txt): with two or more waves per SIMD, add/sub, and/or/xor/
+// Result on MI355X (the output is kept under profiles/): with two or more waves per SIMD, add/sub, and/or/xor/
 // not, v_bitop3_b32, right shifts, v_mov and f32 add/mul/fma on register or literal operands issue at ~2.4
 // cycles; everything else (left shifts, 24/32-bit multiplies, dot2/dot4, packed 16-bit, bfe, alignbit, perm,
 // ffbh, min/max, the other three-operand integer forms, cvt, DPP moves, and any instruction with a scalar
