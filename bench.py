@@ -33,6 +33,8 @@ def parse_args():
     ap.add_argument("--content", choices=["natural", "noise"], default="natural")
     ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the batch timed on the CPU oracle")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--persistence", type=float, default=None,
+                    help="octave amplitude ratio of the natural-like generator (default 0.7; larger = more detail)")
     ap.add_argument("--quant", type=int, default=1, help="every quantiser table entry (1: the RTL default)")
     ap.add_argument("--ws-mb", type=int, default=0, help="workspace limit in MiB (0: library default)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -105,6 +107,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     pkg = importlib.import_module("jpeg-encoder_amd")
 
+    if args.persistence is not None:
+        pkg.synth.PERSISTENCE = args.persistence
     w, h, nf = args.width, args.height, args.frames
     px_per_frame = w * h
     # this rank's shard: frames [rank*nf, (rank+1)*nf) of the global batch, seeds 1000 + global index
@@ -169,7 +173,9 @@ def main():
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "config": {"workload": "%d x %dx%d RGB frames per GPU, %s content, %s quant tables; "
                                "8 GPUs = the 8192-frame 1080p configuration, sharded by image"
-                               % (nf, w, h, "natural-like" if args.content == "natural" else "uniform-noise",
+                               % (nf, w, h, ("natural-like" if args.persistence is None else
+                                             "natural-like (persistence %.2f)" % args.persistence)
+                                  if args.content == "natural" else "uniform-noise",
                                   "RTL default (all-ones)" if args.quant == 1 else "all-%d" % args.quant),
                    "frames_per_gpu": nf, "width": w, "height": h, "sharding": "independent images, no collective"},
         "all_images_ok": ok, "out_bytes_per_pixel": round(out_bytes_per_px, 4),
