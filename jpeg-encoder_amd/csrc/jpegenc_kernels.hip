@@ -509,13 +509,18 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
     uint32_t tail8 = 0;        // last 8 bits of the stream so far (uniform)
 
     // Tier loop: n_groups = 1, 2 or 4 groups of 64/n_groups lanes coding at once (see kRegionWords).
+    // Between the first tier and the group tiers: when a lane overflowed its region but the chunk as a whole
+    // fits, the chunk is redone once with every lane given exactly the words it needs (`fit`; the lengths
+    // are known from the first pass, which counts every lane's bits even when it cannot store them).
     int n_groups = 1;
+    bool fit = false;
+    uint32_t fit_base = 0, fit_cap = 0;
     for (int g = 0; g < n_groups; ++g) {
         const int lanes_per_group = 64 / n_groups;
         const uint32_t stride = (uint32_t)kRegionWords * (uint32_t)n_groups;
-        const uint32_t cap = stride - 2u;
+        const uint32_t cap = fit ? fit_cap : stride - 2u;
         const bool active = valid && (lane / lanes_per_group) == g;
-        const uint32_t base = (uint32_t)(lane & (lanes_per_group - 1)) * stride;
+        const uint32_t base = fit ? fit_base : (uint32_t)(lane & (lanes_per_group - 1)) * stride;
         // region: word 0 takes the stores of the bit writer that are not meant to land, words [1, 1+cap)
         // the string, one more word the zero behind a full string; lanes of other groups count their
         // bits but store nothing
@@ -577,7 +582,7 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
             int pred = __shfl_up(x[0], 1);
             const int h = (comp == 0) ? halo[0] : (comp == 1) ? halo[1] : halo[2];
             if (lane == 0) pred = h;
-            if (n_groups == 1)
+            if (n_groups == 1 && !fit)
                 encode_block<false>(x, pred, comp == 1 && cb_quirk, htab, hlen, priv, bw);
             else
                 encode_block<true>(x, pred, comp == 1 && cb_quirk, htab, hlen, priv, bw);
@@ -590,8 +595,18 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
             if ((bw.T & 31u) != 0) priv[(bw.T >> 5) + 1u] = (uint32_t)bw.win << ((0u - bw.T) & 31u);
             priv[((bw.T + 31u) >> 5) + 1u] = 0u;  // one zero word behind the string
         }
-        if (n_groups == 1 && __any((int)(Lall > cap * 32u))) {
-            n_groups = __any((int)(Lall > (2u * kRegionWords - 2u) * 32u)) ? 4 : 2;
+        if (n_groups == 1 && !fit && __any((int)(Lall > cap * 32u))) {
+            // words per lane: the unread word 0, the string, the zero word behind it
+            const uint32_t need = ((Lall + 31u) >> 5) + 2u;
+            uint32_t need_total;
+            const uint32_t need_off = wave_excl_scan_u32(need, lane, &need_total);
+            if (need_total <= 64u * kRegionWords) {
+                fit = true;
+                fit_base = need_off;
+                fit_cap = need - 2u;
+            } else {
+                n_groups = __any((int)(Lall > (2u * kRegionWords - 2u) * 32u)) ? 4 : 2;
+            }
             g = -1;  // restart the chunk on that tier
             __syncthreads();
             continue;
@@ -606,7 +621,7 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
         // string never moves to a higher address and all reads of a step precede its writes.
         uint32_t gtotal;
         const uint32_t off = wave_excl_scan_u32(L, lane, &gtotal);
-        if (n_groups == 1) {
+        if (n_groups == 1 && !fit) {
             // First tier, every lane at once: each lane takes its whole string (at most kOwnWords words,
             // the last one zero) into registers, the destination range is cleared, and every lane ORs
             // its words, shifted to its bit offset, into place.  Words shared by neighbouring strings
@@ -636,12 +651,12 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
         }
         const int first = g * lanes_per_group;
         uint32_t tailw = 0;
-        for (int m = 0; n_groups != 1 && m < lanes_per_group; ++m) {
+        for (int m = 0; (n_groups != 1 || fit) && m < lanes_per_group; ++m) {
             const int M = first + m;
             const uint32_t LM = readlane_u32(L, M);
             if (LM == 0) continue;  // uniform
             const uint32_t oM = readlane_u32(off, M);
-            const uint32_t bM = (uint32_t)m * stride + 1u;
+            const uint32_t bM = readlane_u32(base, M) + 1u;
             const uint32_t s = oM & 31u, d0 = oM >> 5;
             const uint32_t nw = (LM + 31u) >> 5;      // source words
             const uint32_t nd = (s + LM + 31u) >> 5;  // destination words touched
