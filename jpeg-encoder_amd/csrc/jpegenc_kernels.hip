@@ -305,7 +305,7 @@ __device__ __forceinline__ uint32_t amp_bits(int t, uint32_t size) {
     return __builtin_amdgcn_ubfe((uint32_t)t, 0u, size);
 }
 
-template <bool GUARD>
+template <bool GUARD, bool SKIP>
 __device__ __forceinline__ void encode_block(const int (&blk)[64], int dc_pred, bool cb_eob_quirk,
                                              const uint32_t* htab, const uint8_t* hlen, uint32_t* priv,
                                              BitWriter& bw) {
@@ -335,17 +335,29 @@ __device__ __forceinline__ void encode_block(const int (&blk)[64], int dc_pred, 
     // sets end_of_block to 1 always wins (cb_huff.sv:238-243)
     const uint32_t eob_c = (cb_eob_quirk || t67 == 0) ? 16u : 0u;
 
+    // a run of 15 zeros cannot complete before k = 16, so the flag only matters from there on
+    auto eob_of = [&](int k) { return (k < 16) ? 0u : (k + 2 < 32) ? eob_a : (k + 2 < 48) ? eob_b : eob_c; };
     uint32_t r5 = 0;  // run << 5
     uint32_t run_mask = 0x1E0u;
     asm volatile("" : "+v"(run_mask));  // kept in a vector register: a scalar operand would halve the issue rate
 #pragma unroll
     for (int k = 1; k <= 62; ++k) {
         const int v = blk[kZZ[k]];
+        if constexpr (SKIP) {
+            // Quantised content: most of the time no lane of the wave has anything to emit at this
+            // position (a zero emits only as the 16th of a run outside end_of_block) -- then only the
+            // run counters move.  With all-ones tables the test would almost never succeed, so that
+            // variant does not make it.
+            const bool emits = (v != 0) || ((r5 | eob_of(k)) == 0x1E0u);
+            if (!__any((int)emits)) {
+                r5 = (r5 + 32u) & 0x1E0u;
+                continue;
+            }
+        }
         const int t = amp_src(v);
         const int lead = lead_bits(t);
         const uint32_t size = mag_bits(lead);
-        // a run of 15 zeros cannot complete before k = 16, so the flag only matters from there on
-        const uint32_t eob = (k < 16) ? 0u : (k + 2 < 32) ? eob_a : (k + 2 < 48) ? eob_b : eob_c;
+        const uint32_t eob = eob_of(k);
         const uint32_t at = or3_fast(r5, size, eob);
         bw_emit<GUARD>(bw, htab[at], amp_bits(t, size), hlen[at], priv);
         // zero coefficient (lead == -1, all ones): run + 1 modulo 16; otherwise the run restarts (lead is
@@ -583,9 +595,9 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
             const int h = (comp == 0) ? halo[0] : (comp == 1) ? halo[1] : halo[2];
             if (lane == 0) pred = h;
             if (n_groups == 1 && !fit)
-                encode_block<false>(x, pred, comp == 1 && cb_quirk, htab, hlen, priv, bw);
+                encode_block<false, QUANT>(x, pred, comp == 1 && cb_quirk, htab, hlen, priv, bw);
             else
-                encode_block<true>(x, pred, comp == 1 && cb_quirk, htab, hlen, priv, bw);
+                encode_block<true, QUANT>(x, pred, comp == 1 && cb_quirk, htab, hlen, priv, bw);
         }
         // Every lane counts its bits whether or not it may store them, so the first pass already knows
         // which tier the chunk needs.
