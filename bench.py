@@ -100,9 +100,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = "nccl"
+    if os.environ.get("JPEGENC_BENCH_REHEARSAL") == "1":
+        # rehearsal of the multi-rank path on a one-GPU box: every rank uses GPU 0, collectives over gloo
+        local_rank, backend = 0, "gloo"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pkg = importlib.import_module("jpeg-encoder_amd")

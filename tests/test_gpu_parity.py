@@ -228,6 +228,27 @@ def test_bands_give_the_whole_images_stream(enc):
         assert np.array_equal(words, want)
 
 
+def test_segment_calls_out_of_order_and_too_small():
+    pkg = load_pkg()
+    img = np.random.default_rng(71).integers(0, 256, (32, 64, 3), dtype=np.uint8)
+    with pkg.JpegTop() as e:
+        with pytest.raises(pkg.JpegEncError) as err:
+            e.segment_count(0, 0)
+        assert err.value.code == pkg.E_STATE
+        bits, tail = e.segment_encode(img, 0, 32)
+        with pytest.raises(pkg.JpegEncError) as err:
+            e.segment_write(0, True, 64)  # the count step was left out
+        assert err.value.code == pkg.E_STATE
+        e.segment_count(0, 0)
+        with pytest.raises(pkg.JpegEncError) as err:
+            e.segment_write(0, True, 8)   # far too small: reported, nothing beyond 8 words touched
+        assert err.value.code == pkg.E_TOO_SMALL
+        # the context is usable afterwards
+        words, res = e.encode(img)
+        assert_same(words, res, img)
+        assert int(res["total_bits_unstuffed"]) == bits
+
+
 def test_output_too_small_is_reported_not_overrun(enc):
     pkg = load_pkg()
     rgb = np.random.default_rng(5).integers(0, 256, (64, 64, 3), dtype=np.uint8)
