@@ -161,7 +161,7 @@ int jpegenc_kernel_times(jpegenc_ctx* ctx, uint64_t launches[JPEGENC_N_KERNELS],
                          int reset);
 const char* jpegenc_kernel_name(int index);
 
-/* Scratch memory budget in bytes for the intermediate chunk streams (default 4 GiB); a batch is
+/* Scratch memory budget in bytes for the intermediate chunk streams (default 32 GiB); a batch is
  * processed in sub-batches that fit. */
 int jpegenc_set_workspace_limit(jpegenc_ctx* ctx, size_t bytes);
 

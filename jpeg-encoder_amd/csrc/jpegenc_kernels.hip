@@ -546,8 +546,9 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
         for (int comp = 0; comp < 3; ++comp) {
             const CompCoef cc = comp_coef(comp);
             int x[64];
-            // The MCU's 192 bytes are re-read for every component (served by L2 after the first pass):
-            // holding them in 48 registers across the whole chunk costs more occupancy than the reloads.
+            // The MCU's 192 bytes are fetched again for every component (mostly from L2): holding them in 48
+            // registers across the components spills at the register budget of three waves per SIMD,
+            // and the scratch traffic then exceeds the saved fetches (measured).
             uint32_t raw[48];
             load_mcu<ALIGN>(src, p.stride, raw);
             // Two separately compiled bodies (shifts are immediates).  The differing asm comments keep
