@@ -51,7 +51,12 @@ typedef struct jpegenc_config {
     uint8_t quirk_cb_6d64;   /* 1 = cb_huff's 6'd64 literal as written (cb_huff.sv:238,241) */
     uint8_t quirk_ydct_zext; /* must be 0: the luma zero-extension accident (y_dct.sv:65-66,171-177)
                                 is repaired; 1 is rejected with JPEGENC_E_UNSUPPORTED */
-    uint8_t reserved;
+    uint8_t quant_index_order; /* the quantiser wrappers hook scalar ports to array ports (yd_q_h.sv:90-117 vs
+                                  y_quantizer.sv:21-22), so which table entry meets which frequency is
+                                  not fixed by the text.  0 (default) = the index the quantiser itself
+                                  uses, entry [i*8+j] for Z{i+1}{j+1}, i horizontal; 1 = the conventional
+                                  row-major order, entry [a*8+b] for vertical frequency a, horizontal b.
+                                  Same stream for symmetric tables, and for the all-ones default. */
     int32_t device;          /* HIP device ordinal */
 } jpegenc_config;
 

@@ -303,6 +303,7 @@ int jpegenc_create(jpegenc_ctx** out, const jpegenc_config* cfg) {
     if (!out || !cfg) return JPEGENC_E_BAD_ARG;
     *out = nullptr;
     if (cfg->quirk_ydct_zext) return JPEGENC_E_UNSUPPORTED;
+    if (cfg->quant_index_order > 1) return JPEGENC_E_BAD_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return JPEGENC_E_HIP;
     if (cfg->device < 0 || cfg->device >= ndev) return JPEGENC_E_BAD_ARG;
@@ -334,7 +335,7 @@ int jpegenc_create(jpegenc_ctx** out, const jpegenc_config* cfg) {
             for (int b = 0; b < 8; ++b) {
                 // Huffman-input position (a vertical, b horizontal) is DCT output Z{b+1}{a+1}, which the
                 // quantiser scales with table entry [b*8+a] (y_quantizer.sv:40-43, yd_q_h.sv:120-135).
-                const uint16_t q = cfg->qtab[c][b * 8 + a];
+                const uint16_t q = cfg->quant_index_order ? cfg->qtab[c][a * 8 + b] : cfg->qtab[c][b * 8 + a];
                 if (q != 1) all_ones = false;
                 qmul[c * 64 + a * 8 + b] = q ? int32_t(4096 / q) : 0;
             }

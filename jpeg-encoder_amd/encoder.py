@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
 class Config(C.Structure):
     _fields_ = [("qtab", (C.c_uint16 * 64) * 3),
                 ("quirk_rgb_wrap", C.c_uint8), ("quirk_cb_6d64", C.c_uint8),
-                ("quirk_ydct_zext", C.c_uint8), ("reserved", C.c_uint8),
+                ("quirk_ydct_zext", C.c_uint8), ("quant_index_order", C.c_uint8),
                 ("device", C.c_int32)]
 
 
@@ -115,7 +115,7 @@ def max_words(w, h):
 class JpegTop:
     """One instance of the jpeg_top path bound to a GPU (one context = one device + one stream)."""
 
-    def __init__(self, qtabs=None, rgb_wrap=True, cb_6d64=True, device=0, stream=None):
+    def __init__(self, qtabs=None, rgb_wrap=True, cb_6d64=True, device=0, stream=None, quant_index_order=0):
         self.lib = load_library()
         cfg = Config()
         self.lib.jpegenc_default_config(C.byref(cfg))
@@ -125,6 +125,7 @@ class JpegTop:
                     cfg.qtab[c][i] = int(qtabs[c][i])
         cfg.quirk_rgb_wrap = int(rgb_wrap)
         cfg.quirk_cb_6d64 = int(cb_6d64)
+        cfg.quant_index_order = int(quant_index_order)
         cfg.device = int(device)
         self.device = int(device)
         self._ctx = C.c_void_p()

@@ -41,15 +41,19 @@ def scan_bytes(words, n_full_words, tail_bits):
     return bytes(raw)
 
 
-def wrap_jfif(words, n_full_words, tail_bits, width, height, qtabs=None):
+def wrap_jfif(words, n_full_words, tail_bits, width, height, qtabs=None, quant_index_order=0):
     """Returns a complete baseline JPEG file.  qtabs: three 64-entry tables in the configuration's
-    order (entry [i*8+j] scales horizontal frequency i, vertical frequency j), default all ones."""
+    order (quant_index_order 0: entry [i*8+j] scales horizontal frequency i, vertical frequency j; 1:
+    entry [a*8+b] scales vertical a, horizontal b), default all ones."""
     out = bytearray(b"\xFF\xD8")
     out += _segment(0xE0, b"JFIF\x00\x01\x01\x00\x00\x01\x00\x01\x00\x00")
     for c in range(3):
         q = [1] * 64 if qtabs is None else [int(v) for v in qtabs[c]]
         # zig-zag position k is (row a = vertical, col b = horizontal) = ZIGZAG[k]; config index b*8+a
-        zz = [min(255, max(1, q[(ZIGZAG[k] % 8) * 8 + ZIGZAG[k] // 8])) for k in range(64)]
+        if quant_index_order:
+            zz = [min(255, max(1, q[ZIGZAG[k]])) for k in range(64)]
+        else:
+            zz = [min(255, max(1, q[(ZIGZAG[k] % 8) * 8 + ZIGZAG[k] // 8])) for k in range(64)]
         out += _segment(0xDB, bytes([c]) + bytes(zz))
     sof = struct.pack(">BHHB", 8, height, width, 3)
     for c in range(3):

@@ -381,7 +381,14 @@ void ref_quantize(const int32_t F[64], const uint16_t qtab[64], int32_t Q[64]) {
 void ref_block_coeffs(const ref_config* cfg, int comp, const uint8_t x[64], int32_t blk[64]) {
     int32_t F[64], Q[64];
     ref_dct8x8(cfg, x, comp == 0, F);
-    ref_quantize(F, cfg->qtab[comp], Q);
+    if (cfg->quant_index_order) {
+        uint16_t qt[64];  // F[k*8+j] has k horizontal: transpose the row-major (vertical, horizontal) table
+        for (int k = 0; k < 8; ++k)
+            for (int j = 0; j < 8; ++j) qt[k * 8 + j] = cfg->qtab[comp][j * 8 + k];
+        ref_quantize(F, qt, Q);
+    } else {
+        ref_quantize(F, cfg->qtab[comp], Q);
+    }
     // Wrapper transpose yd_q_h.sv:120-135 (cbd_q_h.sv:114-128, crd_q_h.sv:112-126):
     // huff.Y{a}{b} = Q{b}{a}, so blk[a][b] is (vertical a, horizontal b).
     for (int a = 0; a < 8; ++a)

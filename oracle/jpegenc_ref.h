@@ -33,7 +33,9 @@ typedef struct ref_config {
     uint8_t quirk_rgb_wrap;  /* Q1, default 1 (as written) */
     uint8_t quirk_cb_6d64;   /* Q3, default 1 (as written) */
     uint8_t quirk_ydct_zext; /* Q6, default 0 (repaired)   */
-    uint8_t reserved;
+    uint8_t quant_index_order; /* 0 (default): entry [i*8+j] scales Z{i+1}{j+1}, i horizontal; 1: entry
+                                  [a*8+b] scales vertical frequency a, horizontal b (the hookup of the
+                                  quantiser wrappers, yd_q_h.sv:90-117, leaves it open) */
 } ref_config;
 
 typedef struct ref_result {

@@ -14,7 +14,7 @@ _SO = os.path.join(_ORACLE_DIR, "libjpegenc_oracle.so")
 class RefConfig(C.Structure):
     _fields_ = [("qtab", (C.c_uint16 * 64) * 3),
                 ("quirk_rgb_wrap", C.c_uint8), ("quirk_cb_6d64", C.c_uint8),
-                ("quirk_ydct_zext", C.c_uint8), ("reserved", C.c_uint8)]
+                ("quirk_ydct_zext", C.c_uint8), ("quant_index_order", C.c_uint8)]
 
 
 class RefResult(C.Structure):
@@ -65,7 +65,7 @@ def lib():
     return _lib
 
 
-def default_config(qtabs=None, rgb_wrap=True, cb_6d64=True, ydct_zext=False):
+def default_config(qtabs=None, rgb_wrap=True, cb_6d64=True, ydct_zext=False, quant_index_order=0):
     cfg = RefConfig()
     lib().ref_default_config(C.byref(cfg))
     if qtabs is not None:
@@ -75,6 +75,7 @@ def default_config(qtabs=None, rgb_wrap=True, cb_6d64=True, ydct_zext=False):
     cfg.quirk_rgb_wrap = int(rgb_wrap)
     cfg.quirk_cb_6d64 = int(cb_6d64)
     cfg.quirk_ydct_zext = int(ydct_zext)
+    cfg.quant_index_order = int(quant_index_order)
     return cfg
 
 

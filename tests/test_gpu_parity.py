@@ -145,11 +145,11 @@ def test_quirk_switches_and_quant_tables():
     for c in range(3):
         sparse[c][rng.integers(0, 64, 6)] = rng.integers(1, 8, 6)
     cases = [dict(), dict(rgb_wrap=False), dict(cb_6d64=False), dict(qtabs=qt), dict(qtabs=sparse),
-             dict(qtabs=sparse, cb_6d64=False)]
+             dict(qtabs=sparse, cb_6d64=False), dict(qtabs=qt, quant_index_order=1)]
     for kw in cases:
         with pkg.JpegTop(**kw) as e:
             cfg = O.default_config(qtabs=kw.get("qtabs"), rgb_wrap=kw.get("rgb_wrap", True),
-                                   cb_6d64=kw.get("cb_6d64", True))
+                                   cb_6d64=kw.get("cb_6d64", True), quant_index_order=kw.get("quant_index_order", 0))
             for img in (rgb, noise):
                 words, res = e.encode(img)
                 assert_same(words, res, img, cfg)

@@ -57,3 +57,24 @@ def test_noise_decodes():
     words, res = O.encode(rgb)
     out = decode(pkg.jfif.wrap_jfif(words, res.n_full_words, res.tail_bits, 32, 32))
     assert psnr(out, rgb) > 30.0
+
+
+def test_asymmetric_tables_in_both_index_orders():
+    """A table that is coarse for high horizontal frequencies only.  Written in the conventional row-major
+    (vertical, horizontal) order and passed with quant_index_order = 1 it must give the stream of its
+    transpose under the default order, and an external decoder fed the same table must reproduce the image:
+    that pins which table entry meets which frequency."""
+    pkg = load_pkg()
+    rgb = natural_like(64, 64, 9)
+    conv = np.array([[32 if b >= 3 else 2 for b in range(8)] for a in range(8)]).reshape(64)  # [a*8+b]
+    as_hooked = conv.reshape(8, 8).T.reshape(64)                                            # [i*8+j], i horizontal
+    w1, r1 = O.encode(rgb, O.default_config(qtabs=[conv] * 3, quant_index_order=1))
+    w0, r0 = O.encode(rgb, O.default_config(qtabs=[as_hooked] * 3))
+    assert np.array_equal(w0, w1) and r0.tail_bits == r1.tail_bits
+    wrong, _ = O.encode(rgb, O.default_config(qtabs=[conv] * 3))  # the same numbers read the other way round
+    assert not np.array_equal(wrong[:64], w1[:64])
+    good = decode(pkg.jfif.wrap_jfif(w1, r1.n_full_words, r1.tail_bits, 64, 64, qtabs=[conv] * 3, quant_index_order=1))
+    also = decode(pkg.jfif.wrap_jfif(w0, r0.n_full_words, r0.tail_bits, 64, 64, qtabs=[as_hooked] * 3))
+    bad = decode(pkg.jfif.wrap_jfif(w1, r1.n_full_words, r1.tail_bits, 64, 64, qtabs=[as_hooked] * 3, quant_index_order=1))
+    assert np.array_equal(good, also)
+    assert psnr(good, rgb) > 28.0 and psnr(good, rgb) > psnr(bad, rgb) + 3.0
