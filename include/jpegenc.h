@@ -35,6 +35,9 @@ extern "C" {
 
 /* flags for the encode calls */
 #define JPEGENC_HOST_PTRS 0u   /* rgb / words_out / results are host memory (copied, call blocks) */
+#define JPEGENC_PAD_EDGES 4u   /* extension, not in jpeg_top (which has no edge handling): w and h need not be
+                                  multiples of 8; the last column and row are repeated up to the next multiples
+                                  and the padded image is coded (jpegenc_encode_rgb8 / _batch only) */
 #define JPEGENC_DEVICE_PTRS 1u /* all three are device memory on the context's device; the call
                                   only enqueues work on the context's stream */
 

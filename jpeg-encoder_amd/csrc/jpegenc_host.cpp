@@ -95,6 +95,7 @@ struct jpegenc_ctx {
     DevBuf<uint64_t> bit_off, ff_off;
     // staging for host-pointer calls
     DevBuf<uint8_t> in_stage;
+    DevBuf<uint8_t> pad_stage;  // JPEGENC_PAD_EDGES: the images padded to multiples of 8
     DevBuf<uint32_t> out_stage;
     DevBuf<jpegenc_result> res_stage;
 
@@ -246,12 +247,16 @@ int encode_device(jpegenc_ctx* ctx, const uint8_t* rgb, int n_images, int w, int
     return JPEGENC_OK;
 }
 
-int check_dims(const void* rgb, int n, int w, int h, ptrdiff_t stride, const void* words, const void* results) {
+int check_dims(const void* rgb, int n, int w, int h, ptrdiff_t stride, const void* words, const void* results,
+               bool pad_edges = false) {
     if (!rgb || !words || !results) return JPEGENC_E_BAD_ARG;
-    if (n <= 0 || w <= 0 || h <= 0 || (w % 8) || (h % 8)) return JPEGENC_E_BAD_ARG;
+    if (n <= 0 || w <= 0 || h <= 0 || (!pad_edges && ((w % 8) || (h % 8)))) return JPEGENC_E_BAD_ARG;
     if (stride < ptrdiff_t(w) * 3) return JPEGENC_E_BAD_ARG;
     return JPEGENC_OK;
 }
+
+int encode_staged(jpegenc_ctx* ctx, const uint8_t* d_rgb, int n_images, int w, int h, uint32_t* words, size_t cap_words,
+                  jpegenc_result* results);
 
 int encode_host(jpegenc_ctx* ctx, const uint8_t* rgb, int n_images, int w, int h, ptrdiff_t stride,
                 ptrdiff_t image_stride, uint32_t* words, size_t cap_words, jpegenc_result* results) {
@@ -263,8 +268,18 @@ int encode_host(jpegenc_ctx* ctx, const uint8_t* rgb, int n_images, int w, int h
     for (int i = 0; i < n_images; ++i)
         HIPCHK(ctx, hipMemcpy2DAsync(ctx->in_stage.p + img_bytes * size_t(i), row, rgb + int64_t(i) * image_stride,
                                      size_t(stride), row, size_t(h), hipMemcpyHostToDevice, ctx->stream));
-    int rc = encode_device(ctx, ctx->in_stage.p, n_images, w, h, ptrdiff_t(row), ptrdiff_t(img_bytes),
-                           ctx->out_stage.p, cap_words, ctx->res_stage.p);
+    return encode_staged(ctx, ctx->in_stage.p, n_images, w, h, words, cap_words, results);
+}
+
+// Device-resident, densely packed input; output and results go back to host memory.
+int encode_staged(jpegenc_ctx* ctx, const uint8_t* d_rgb, int n_images, int w, int h, uint32_t* words, size_t cap_words,
+                  jpegenc_result* results) {
+    const size_t row = size_t(w) * 3;
+    const size_t img_bytes = row * size_t(h);
+    HIPCHK(ctx, ctx->out_stage.reserve(cap_words * size_t(n_images)));
+    HIPCHK(ctx, ctx->res_stage.reserve(size_t(n_images)));
+    int rc = encode_device(ctx, d_rgb, n_images, w, h, ptrdiff_t(row), ptrdiff_t(img_bytes), ctx->out_stage.p, cap_words,
+                           ctx->res_stage.p);
     if (rc != JPEGENC_OK) return rc;
     HIPCHK(ctx, hipMemcpyAsync(results, ctx->res_stage.p, sizeof(jpegenc_result) * size_t(n_images),
                                hipMemcpyDeviceToHost, ctx->stream));
@@ -368,6 +383,7 @@ int jpegenc_destroy(jpegenc_ctx* ctx) {
     ctx->bit_off.release();
     ctx->ff_off.release();
     ctx->in_stage.release();
+    ctx->pad_stage.release();
     ctx->out_stage.release();
     ctx->res_stage.release();
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -390,7 +406,7 @@ int jpegenc_synchronize(jpegenc_ctx* ctx) {
 
 size_t jpegenc_max_words(int w, int h) {
     if (w <= 0 || h <= 0) return 0;
-    const uint64_t mcus = uint64_t(w / 8) * uint64_t(h / 8);
+    const uint64_t mcus = uint64_t((w + 7) / 8) * uint64_t((h + 7) / 8);
     return size_t((mcus * uint64_t(kMaxMcuBits) * 2 + 31) / 32 + 1);
 }
 
@@ -398,12 +414,37 @@ int jpegenc_encode_batch(jpegenc_ctx* ctx, const uint8_t* rgb, int n_images, int
                          ptrdiff_t image_stride, uint32_t flags, uint32_t* words_out, size_t cap_words_per_image,
                          jpegenc_result* results) {
     if (!ctx) return JPEGENC_E_BAD_ARG;
-    int rc = check_dims(rgb, n_images, w, h, stride, words_out, results);
+    const bool pad = (flags & JPEGENC_PAD_EDGES) && ((w % 8) || (h % 8));
+    int rc = check_dims(rgb, n_images, w, h, stride, words_out, results, pad);
     if (rc != JPEGENC_OK) return rc;
     if (cap_words_per_image == 0) return JPEGENC_E_BAD_ARG;
     if (n_images > 1 && (image_stride < 0 ? -image_stride : image_stride) < stride * ptrdiff_t(h) && image_stride != 0)
         return JPEGENC_E_BAD_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (pad) {
+        // extension (not in jpeg_top): replicate the right and bottom edges up to multiples of 8 on the
+        // device, then code the padded images
+        const int w8 = (w + 7) & ~7, h8 = (h + 7) & ~7;
+        const size_t row = size_t(w) * 3, padded = size_t(w8) * 3 * size_t(h8);
+        const uint8_t* d_src = rgb;
+        ptrdiff_t s_stride = stride, s_istride = image_stride;
+        if (!(flags & JPEGENC_DEVICE_PTRS)) {
+            HIPCHK(ctx, ctx->in_stage.reserve(row * size_t(h) * size_t(n_images)));
+            for (int i = 0; i < n_images; ++i)
+                HIPCHK(ctx, hipMemcpy2DAsync(ctx->in_stage.p + row * size_t(h) * size_t(i), row,
+                                             rgb + int64_t(i) * image_stride, size_t(stride), row, size_t(h),
+                                             hipMemcpyHostToDevice, ctx->stream));
+            d_src = ctx->in_stage.p;
+            s_stride = ptrdiff_t(row);
+            s_istride = ptrdiff_t(row * size_t(h));
+        }
+        HIPCHK(ctx, ctx->pad_stage.reserve(padded * size_t(n_images)));
+        HIPCHK(ctx, launch_pad_edges(d_src, s_stride, s_istride, w, h, n_images, ctx->pad_stage.p, ctx->stream));
+        if (flags & JPEGENC_DEVICE_PTRS)
+            return encode_device(ctx, ctx->pad_stage.p, n_images, w8, h8, ptrdiff_t(w8) * 3, ptrdiff_t(padded), words_out,
+                                 cap_words_per_image, results);
+        return encode_staged(ctx, ctx->pad_stage.p, n_images, w8, h8, words_out, cap_words_per_image, results);
+    }
     if (flags & JPEGENC_DEVICE_PTRS)
         return encode_device(ctx, rgb, n_images, w, h, stride, image_stride, words_out, cap_words_per_image, results);
     return encode_host(ctx, rgb, n_images, w, h, stride, image_stride, words_out, cap_words_per_image, results);

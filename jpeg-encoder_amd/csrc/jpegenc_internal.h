@@ -78,6 +78,9 @@ hipError_t launch_scan(const ScanParams& p, uint32_t n_images, hipStream_t s);
 hipError_t launch_stuff_count(const StuffParams& p, uint32_t n_images, hipStream_t s);
 hipError_t launch_stuff_write(const StuffParams& p, uint32_t n_images, hipStream_t s);
 
+hipError_t launch_pad_edges(const uint8_t* src, int64_t stride, int64_t image_stride, int w, int h, int n_images,
+                            uint8_t* dst, hipStream_t s);
+
 // Host-side table construction (jpegenc_host.cpp).
 void build_htab(uint32_t out[kHtabEntries]);
 

@@ -1093,6 +1093,33 @@ __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_write(StuffParams p,
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_pad_edges: copies images of w x h pixels into images of w8 x h8 (the next multiples of 8), repeating
+// the last column and the last row.  An extension: jpeg_top has no edge handling (a block is 64
+// consecutive samples, cb_dct.sv:478-541) and the entry points reject such sizes unless asked to pad.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pad_edges(const uint8_t* src, int64_t stride, int64_t image_stride, int w, int h,
+                                                   uint8_t* dst, int w8, int h8) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;  // pixel of one padded image
+    const int img = blockIdx.y;
+    if (idx >= (int64_t)w8 * h8) return;
+    const int y = (int)(idx / w8), x = (int)(idx - (int64_t)y * w8);
+    const uint8_t* q = src + (int64_t)img * image_stride + (int64_t)min(y, h - 1) * stride + (int64_t)min(x, w - 1) * 3;
+    uint8_t* o = dst + ((int64_t)img * h8 * w8 + idx) * 3;
+    o[0] = q[0];
+    o[1] = q[1];
+    o[2] = q[2];
+}
+
+hipError_t launch_pad_edges(const uint8_t* src, int64_t stride, int64_t image_stride, int w, int h, int n_images,
+                            uint8_t* dst, hipStream_t s) {
+    const int w8 = (w + 7) & ~7, h8 = (h + 7) & ~7;
+    const int64_t px = (int64_t)w8 * h8;
+    hipLaunchKernelGGL(k_pad_edges, dim3((unsigned)((px + 255) / 256), (unsigned)n_images), dim3(256), 0, s, src, stride,
+                       image_stride, w, h, dst, w8, h8);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 template <int ALIGN, bool QUANT>

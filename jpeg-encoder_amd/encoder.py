@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libjpegenc.so")
 
 OK, E_BAD_ARG, E_TOO_SMALL, E_HIP, E_UNSUPPORTED, E_NOMEM, E_STATE = 0, -1, -2, -3, -4, -5, -6
 HOST_PTRS, DEVICE_PTRS = 0, 1
+PAD_EDGES = 4
 SEG_CONTINUES = 2
 N_KERNELS = 4
 
@@ -176,19 +177,22 @@ class JpegTop:
         return {self.lib.jpegenc_kernel_name(i).decode(): (int(n[i]), float(ms[i])) for i in range(N_KERNELS)}
 
     # -- raster API (host memory) -----------------------------------------------------------
-    def encode(self, rgb, cap_words=None):
+    def encode(self, rgb, cap_words=None, pad_edges=False):
         """rgb: (h, w, 3) uint8 numpy array.  Returns (words incl. tail word, result record)."""
-        words, res = self.encode_batch(rgb[None], cap_words)
+        words, res = self.encode_batch(rgb[None], cap_words, pad_edges=pad_edges)
         return words[0], res[0]
 
-    def encode_batch(self, rgb, cap_words=None, allow_too_small=False):
-        """rgb: (n, h, w, 3) uint8 numpy array.  Returns (list of word arrays, results array)."""
+    def encode_batch(self, rgb, cap_words=None, allow_too_small=False, pad_edges=False):
+        """rgb: (n, h, w, 3) uint8 numpy array.  Returns (list of word arrays, results array).
+        pad_edges (an extension the RTL does not have): h and w need not be multiples of 8, the last row
+        and column are repeated up to the next multiples and that padded image is what gets coded."""
         rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
         n, h, w, _ = rgb.shape
         cap = int(cap_words or max_words(w, h))
         words = np.zeros((n, cap), dtype=np.uint32)
         res = np.zeros(n, dtype=RESULT_DTYPE)
-        rc = self.lib.jpegenc_encode_batch(self._ctx, rgb.ctypes.data, n, w, h, w * 3, h * w * 3, HOST_PTRS,
+        rc = self.lib.jpegenc_encode_batch(self._ctx, rgb.ctypes.data, n, w, h, w * 3, h * w * 3,
+                                           HOST_PTRS | (PAD_EDGES if pad_edges else 0),
                                            words.ctypes.data, cap, res.ctypes.data)
         self._check(rc, allow=(E_TOO_SMALL,) if allow_too_small else ())
         out = []

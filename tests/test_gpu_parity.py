@@ -228,6 +228,42 @@ def test_bands_give_the_whole_images_stream(enc):
         assert np.array_equal(words, want)
 
 
+def test_edge_replication_extension(enc):
+    """Sizes that are not multiples of 8 are rejected as the RTL would have it, unless the caller asks for
+    the extension: then the stream is that of the image with its last row and column repeated."""
+    pkg = load_pkg()
+    rng = np.random.default_rng(91)
+    for h, w in ((13, 21), (8, 9), (65, 64), (100, 203), (1, 1)):
+        rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        with pytest.raises(pkg.JpegEncError) as err:
+            enc.encode(rgb)
+        assert err.value.code == pkg.E_BAD_ARG
+        padded = np.pad(rgb, ((0, -h % 8), (0, -w % 8), (0, 0)), mode="edge")
+        words, res = enc.encode(rgb, pad_edges=True)
+        assert_same(words, res, padded)
+    batch = rng.integers(0, 256, (3, 30, 50, 3), dtype=np.uint8)
+    words, res = enc.encode_batch(batch, pad_edges=True)
+    for i in range(3):
+        assert_same(words[i], res[i], np.pad(batch[i], ((0, 2), (0, 6), (0, 0)), mode="edge"))
+    # device pointers, strided rows
+    torch = pytest.importorskip("torch")
+    h, w, stride = 19, 45, 45 * 3 + 5
+    buf = rng.integers(0, 256, (h, stride), dtype=np.uint8)
+    rgb = np.ascontiguousarray(buf[:, :w * 3].reshape(h, w, 3))
+    d_in = torch.from_numpy(buf).to("cuda:0")
+    cap = pkg.max_words(w, h)
+    d_words = torch.zeros(cap, dtype=torch.int32, device="cuda:0")
+    d_res = torch.zeros(32, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    rc = enc.lib.jpegenc_encode_rgb8(enc._ctx, d_in.data_ptr(), w, h, stride, pkg.DEVICE_PTRS | pkg.PAD_EDGES,
+                                     d_words.data_ptr(), cap, d_res.data_ptr())
+    assert rc == 0
+    enc.synchronize()
+    r = d_res.cpu().numpy().view(pkg.RESULT_DTYPE)[0]
+    k = int(r["n_full_words"]) + (1 if r["tail_bits"] else 0)
+    assert_same(d_words.cpu().numpy().view(np.uint32)[:k], r, np.pad(rgb, ((0, 5), (0, 3), (0, 0)), mode="edge"))
+
+
 def test_segment_calls_out_of_order_and_too_small():
     pkg = load_pkg()
     img = np.random.default_rng(71).integers(0, 256, (32, 64, 3), dtype=np.uint8)

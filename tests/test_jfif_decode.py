@@ -78,3 +78,14 @@ def test_asymmetric_tables_in_both_index_orders():
     bad = decode(pkg.jfif.wrap_jfif(w1, r1.n_full_words, r1.tail_bits, 64, 64, qtabs=[as_hooked] * 3, quant_index_order=1))
     assert np.array_equal(good, also)
     assert psnr(good, rgb) > 28.0 and psnr(good, rgb) > psnr(bad, rgb) + 3.0
+
+
+def test_padded_stream_in_a_container_with_the_true_size():
+    """The edge-replication extension codes the padded image; the JFIF header carries the true size and the
+    decoder crops."""
+    pkg = load_pkg()
+    rgb = natural_like(64, 64, 10)[:53, :37]
+    padded = np.pad(rgb, ((0, 3), (0, 3), (0, 0)), mode="edge")
+    words, res = O.encode(padded)
+    out = decode(pkg.jfif.wrap_jfif(words, res.n_full_words, res.tail_bits, 37, 53))
+    assert out.shape == rgb.shape and psnr(out, rgb) > 40.0
