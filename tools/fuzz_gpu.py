@@ -57,6 +57,8 @@ def main():
         with pkg.JpegTop(**kw) as e:
             for _ in range(4):
                 h, w = 8 * int(rng.integers(1, 40)), 8 * int(rng.integers(1, 70))
+                if rng.random() < 0.03:  # now and then a big one: thousands of chunks, long prefix sums
+                    h, w = 8 * int(rng.integers(100, 140)), 8 * int(rng.integers(200, 260))
                 mode = rng.integers(0, 4)
                 if mode == 3 and h >= 16:  # one stream from bands (fresh contexts, same configuration)
                     img = image(rng, h, w)
