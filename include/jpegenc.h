@@ -31,7 +31,7 @@ extern "C" {
 #define JPEGENC_E_HIP (-3)       /* HIP runtime error or no usable GPU; see jpegenc_last_error */
 #define JPEGENC_E_UNSUPPORTED (-4)
 #define JPEGENC_E_NOMEM (-5)
-#define JPEGENC_E_STATE (-6) /* push/end_of_file protocol misuse */
+#define JPEGENC_E_STATE (-6) /* calls out of order: push/end_of_file protocol, segment calls */
 
 /* flags for the encode calls */
 #define JPEGENC_HOST_PTRS 0u   /* rgb / words_out / results are host memory (copied, call blocks) */

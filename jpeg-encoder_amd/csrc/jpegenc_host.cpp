@@ -135,11 +135,15 @@ int fail_hip(jpegenc_ctx* ctx, hipError_t e, const char* what) {
         if (e_ != hipSuccess) return fail_hip(ctx, e_, #expr);  \
     } while (0)
 
+// Event pairs wait in the context until jpegenc_kernel_times collects them; beyond this many the launches
+// simply go untimed.
+constexpr size_t kMaxPendingEvents = 16384;
+
 struct ProfScope {
     jpegenc_ctx* ctx;
     EventPair ep;
     bool on;
-    ProfScope(jpegenc_ctx* c, int kernel) : ctx(c), on(c->profiling) {
+    ProfScope(jpegenc_ctx* c, int kernel) : ctx(c), on(c->profiling && c->events.size() < kMaxPendingEvents) {
         if (!on) return;
         ep.kernel = kernel;
         if (hipEventCreate(&ep.a) != hipSuccess || hipEventCreate(&ep.b) != hipSuccess) {
@@ -730,7 +734,7 @@ const char* jpegenc_strerror(int code) {
         case JPEGENC_E_HIP: return "HIP error or no usable gfx950 device";
         case JPEGENC_E_UNSUPPORTED: return "unsupported configuration";
         case JPEGENC_E_NOMEM: return "out of memory";
-        case JPEGENC_E_STATE: return "port protocol misuse";
+        case JPEGENC_E_STATE: return "calls out of order (port protocol or segment calls)";
         default: return "unknown error";
     }
 }
