@@ -1114,8 +1114,12 @@ hipError_t launch_pad_edges(const uint8_t* src, int64_t stride, int64_t image_st
                             uint8_t* dst, hipStream_t s) {
     const int w8 = (w + 7) & ~7, h8 = (h + 7) & ~7;
     const int64_t px = (int64_t)w8 * h8;
-    hipLaunchKernelGGL(k_pad_edges, dim3((unsigned)((px + 255) / 256), (unsigned)n_images), dim3(256), 0, s, src, stride,
-                       image_stride, w, h, dst, w8, h8);
+    if ((px + 255) / 256 > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    for (int first = 0; first < n_images; first += 65535) {  // the grid's second dimension ends at 65535
+        const int n = min(65535, n_images - first);
+        hipLaunchKernelGGL(k_pad_edges, dim3((unsigned)((px + 255) / 256), (unsigned)n), dim3(256), 0, s,
+                           src + (int64_t)first * image_stride, stride, image_stride, w, h, dst + (int64_t)first * px * 3, w8, h8);
+    }
     return hipGetLastError();
 }
 
