@@ -233,6 +233,7 @@ int encode_device(jpegenc_ctx* ctx, const uint8_t* rgb, int n_images, int w, int
         tp.pred_tail8 = 0;
         tp.bit_base = tp.ff_base = tp.out_word_base = 0;
         tp.eof = 1;
+        tp.spec_depth = ctx->quant ? 1u : 5u;
         {
             ProfScope ps(ctx, K_STUFF_COUNT);
             HIPCHK(ctx, launch_stuff_count(tp, n, ctx->stream));
@@ -547,6 +548,7 @@ StuffParams segment_params(jpegenc_ctx* ctx) {
     tp.ff_base = 0;
     tp.out_word_base = 0;
     tp.eof = 0;
+    tp.spec_depth = ctx->quant ? 1u : 5u;
     return tp;
 }
 }  // namespace

@@ -69,6 +69,9 @@ struct StuffParams {
     uint64_t ff_base;
     uint64_t out_word_base;
     uint32_t eof;
+    // How many 1 KB steps of a chunk the stuffing kernels request before they know its length: 5 (all of a
+    // photographic chunk at the all-ones tables, 4.4 KB) or 1 (quantised content); selects the kernel variant.
+    uint32_t spec_depth;
 };
 
 // Launchers (defined in jpegenc_kernels.hip).  align = 8, 4 or 1: guaranteed alignment of every

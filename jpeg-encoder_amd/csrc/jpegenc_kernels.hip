@@ -790,6 +790,7 @@ __device__ __forceinline__ uint32_t ff_flags(uint32_t v) {
 // its own; the bytes after it start A = (8 - o % 8) % 8 bits into the chunk's stream, so lane t's four
 // shifted words come from one aligned 16-byte load at word 256 * step + 4 * t and the word behind it.
 // ------------------------------------------------------------------------------------------------
+template <int SPEC>  // 1 KB steps requested before the chunk's length is known
 __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_count(StuffParams p, uint32_t n_chunks) {
     const int lane = threadIdx.x & 63;
     const uint32_t gid = blockIdx.x * kStuffWaves + (threadIdx.x >> 6);
@@ -803,9 +804,11 @@ __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_count(StuffParams p,
     uint32_t w4[kStuffDepth];
 #pragma unroll
     for (int u = 0; u < kStuffDepth; ++u) {
-        const uint32_t* q = S + 256 * u + 4 * lane;
-        w[u] = *reinterpret_cast<const uint4*>(q);
-        w4[u] = q[4];
+        if (u < SPEC) {
+            const uint32_t* q = S + 256 * u + 4 * lane;
+            w[u] = *reinterpret_cast<const uint4*>(q);
+            w4[u] = q[4];
+        }
     }
     const uint32_t c = gid % p.cpi;
     const uint32_t n = p.chunk_bits[gid] & kCountMask;
@@ -821,14 +824,12 @@ __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_count(StuffParams p,
         total = (sb == 0xFFu) ? 1u : 0u;
     }
     for (uint32_t pass = 0; pass < nm; pass += 1024 * kStuffDepth) {
-        if (pass != 0) {
 #pragma unroll
-            for (int u = 0; u < kStuffDepth; ++u) {
-                const uint32_t* q = S + ((pass >> 2) + 256 * u) + 4 * lane;
-                if (pass + 1024u * u < nm) {  // uniform
-                    w[u] = *reinterpret_cast<const uint4*>(q);
-                    w4[u] = q[4];
-                }
+        for (int u = 0; u < kStuffDepth; ++u) {  // what was not requested ahead
+            const uint32_t* q = S + ((pass >> 2) + 256 * u) + 4 * lane;
+            if ((pass != 0 || u >= SPEC) && pass + 1024u * u < nm) {  // uniform
+                w[u] = *reinterpret_cast<const uint4*>(q);
+                w4[u] = q[4];
             }
         }
 #pragma unroll
@@ -865,6 +866,7 @@ __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_count(StuffParams p,
 // (one per wave) and leave it as whole words; the bytes of a word shared with a neighbouring chunk are
 // stored one by one.
 // ------------------------------------------------------------------------------------------------
+template <int SPEC>
 __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_write(StuffParams p, uint32_t n_chunks) {
     __shared__ __attribute__((aligned(16))) uint8_t stage_all[kStuffWaves][kStageBytes];
     uint8_t* const stage = stage_all[threadIdx.x >> 6];
@@ -876,9 +878,11 @@ __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_write(StuffParams p,
     uint32_t w4[kStuffDepth];
 #pragma unroll
     for (int u = 0; u < kStuffDepth; ++u) {  // ahead of the counts and offsets, as in k_stuff_count
-        const uint32_t* q = S + 256 * u + 4 * lane;
-        w[u] = *reinterpret_cast<const uint4*>(q);
-        w4[u] = q[4];
+        if (u < SPEC) {
+            const uint32_t* q = S + 256 * u + 4 * lane;
+            w[u] = *reinterpret_cast<const uint4*>(q);
+            w4[u] = q[4];
+        }
     }
     const uint32_t img = gid / p.cpi;
     const uint32_t c = gid - img * p.cpi;
@@ -963,14 +967,12 @@ __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_write(StuffParams p,
     };
 
     for (uint32_t pass = 0; pass < nm; pass += 1024 * kStuffDepth) {
-        if (pass != 0) {
 #pragma unroll
-            for (int u = 0; u < kStuffDepth; ++u) {
-                const uint32_t* q = S + ((pass >> 2) + 256 * u) + 4 * lane;
-                if (pass + 1024u * u < nm) {  // uniform
-                    w[u] = *reinterpret_cast<const uint4*>(q);
-                    w4[u] = q[4];
-                }
+        for (int u = 0; u < kStuffDepth; ++u) {  // what was not requested ahead
+            const uint32_t* q = S + ((pass >> 2) + 256 * u) + 4 * lane;
+            if ((pass != 0 || u >= SPEC) && pass + 1024u * u < nm) {  // uniform
+                w[u] = *reinterpret_cast<const uint4*>(q);
+                w4[u] = q[4];
             }
         }
 #pragma unroll
@@ -1155,15 +1157,21 @@ hipError_t launch_scan(const ScanParams& p, uint32_t n_images, hipStream_t s) {
 
 hipError_t launch_stuff_count(const StuffParams& p, uint32_t n_images, hipStream_t s) {
     const uint32_t n_chunks = n_images * p.cpi;
-    hipLaunchKernelGGL(k_stuff_count, dim3((n_chunks + kStuffWaves - 1) / kStuffWaves), dim3(64 * kStuffWaves), 0, s, p,
-                       n_chunks);
+    const dim3 grid((n_chunks + kStuffWaves - 1) / kStuffWaves), block(64 * kStuffWaves);
+    if (p.spec_depth >= kStuffDepth)
+        hipLaunchKernelGGL((k_stuff_count<kStuffDepth>), grid, block, 0, s, p, n_chunks);
+    else
+        hipLaunchKernelGGL((k_stuff_count<1>), grid, block, 0, s, p, n_chunks);
     return hipGetLastError();
 }
 
 hipError_t launch_stuff_write(const StuffParams& p, uint32_t n_images, hipStream_t s) {
     const uint32_t n_chunks = n_images * p.cpi;
-    hipLaunchKernelGGL(k_stuff_write, dim3((n_chunks + kStuffWaves - 1) / kStuffWaves), dim3(64 * kStuffWaves), 0, s, p,
-                       n_chunks);
+    const dim3 grid((n_chunks + kStuffWaves - 1) / kStuffWaves), block(64 * kStuffWaves);
+    if (p.spec_depth >= kStuffDepth)
+        hipLaunchKernelGGL((k_stuff_write<kStuffDepth>), grid, block, 0, s, p, n_chunks);
+    else
+        hipLaunchKernelGGL((k_stuff_write<1>), grid, block, 0, s, p, n_chunks);
     return hipGetLastError();
 }
 
