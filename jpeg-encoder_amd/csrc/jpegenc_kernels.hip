@@ -76,14 +76,10 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
 // left shifts, multiplies and anything with a scalar-register operand (measured with tools/micro/valu_cost.hip),
 // and the compiler does not know the difference.
 __device__ __forceinline__ uint32_t or3_fast(uint32_t a, uint32_t b, uint32_t c) {
-    uint32_t r;
-    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xfe" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0xFE);
 }
 __device__ __forceinline__ uint32_t and3_fast(uint32_t a, uint32_t b, uint32_t c) {
-    uint32_t r;
-    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x80" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x80);
 }
 
 __device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int l) {
