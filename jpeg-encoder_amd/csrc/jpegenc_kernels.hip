@@ -312,20 +312,20 @@ __device__ __forceinline__ void encode_block(const int (&blk)[64], int dc_pred, 
         bw_emit<GUARD>(bw, htab[at], amp_bits(t, size), hlen[at], priv);
     }
     // group-of-eight all-zero tests over zig-zag indices 16..63 (cr_huff.sv:190-204)
-    int o2 = 0, o3 = 0, o4 = 0, o5 = 0, o6 = 0, o7 = 0;
+    uint32_t o2 = 0, o3 = 0, o4 = 0, o5 = 0, o6 = 0, o7 = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        o2 |= blk[kZZ[16 + i]];
-        o3 |= blk[kZZ[24 + i]];
-        o4 |= blk[kZZ[32 + i]];
-        o5 |= blk[kZZ[40 + i]];
-        o6 |= blk[kZZ[48 + i]];
-        o7 |= blk[kZZ[56 + i]];
+    for (int i = 0; i < 8; i += 2) {  // two coefficients per three-input OR
+        o2 = or3_fast(o2, (uint32_t)blk[kZZ[16 + i]], (uint32_t)blk[kZZ[17 + i]]);
+        o3 = or3_fast(o3, (uint32_t)blk[kZZ[24 + i]], (uint32_t)blk[kZZ[25 + i]]);
+        o4 = or3_fast(o4, (uint32_t)blk[kZZ[32 + i]], (uint32_t)blk[kZZ[33 + i]]);
+        o5 = or3_fast(o5, (uint32_t)blk[kZZ[40 + i]], (uint32_t)blk[kZZ[41 + i]]);
+        o6 = or3_fast(o6, (uint32_t)blk[kZZ[48 + i]], (uint32_t)blk[kZZ[49 + i]]);
+        o7 = or3_fast(o7, (uint32_t)blk[kZZ[56 + i]], (uint32_t)blk[kZZ[57 + i]]);
     }
-    const int t67 = o6 | o7;
-    const int t47 = o4 | o5 | t67;
+    const uint32_t t67 = o6 | o7;
+    const uint32_t t47 = or3_fast(o4, o5, t67);
     // end_of_block as a table-index bit (256 = set), per block_counter range (cr_huff.sv:213-231)
-    const uint32_t eob_a = ((o2 | o3 | t47) == 0) ? 16u : 0u;  // block_counter < 32
+    const uint32_t eob_a = (or3_fast(o2, o3, t47) == 0) ? 16u : 0u;  // block_counter < 32
     const uint32_t eob_b = (t47 == 0) ? 16u : 0u;              // block_counter < 48
     // block_counter <= 64: groups 7,8 -- except in cb_huff, where `6'd64` is 0 and the branch that
     // sets end_of_block to 1 always wins (cb_huff.sv:238-243)
