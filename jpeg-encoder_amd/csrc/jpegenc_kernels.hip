@@ -188,7 +188,9 @@ __device__ __forceinline__ int pk_sub_x(int a, int b) {
     asm("v_pk_sub_i16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-// acc + a.lo * c.lo + a.hi * c.hi
+// acc + a.lo * c.lo + a.hi * c.hi.  Written as inline asm, so the compiler adds no wait states behind it:
+// v_dot2_i32_i16 needs none (a different instruction may read the result at once, measured with
+// tools/micro/dot_hazard.hip), unlike v_dot4_i32_i8, whose result is only there three instructions later.
 __device__ __forceinline__ int dot2(int a, int c, int acc) {
     int r;
     asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(c), "v"(acc));
@@ -474,10 +476,16 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
     const uint32_t c = gid - img * p.cpi;
     const bool cb_quirk = (p.flags & 2u) != 0;
 
-    for (int i = lane; i < kHtabEntries; i += 64) {
-        const uint32_t e = p.htab[i];
-        htab[i] = e & 0x7FFFFFFu;
-        hlen[i] = (uint8_t)(e >> 27);
+    {
+        static_assert(kHtabEntries % 64 == 0, "whole rounds of 64 lanes");
+        uint32_t e[kHtabEntries / 64];  // all loads in flight at once
+#pragma unroll
+        for (int j = 0; j < kHtabEntries / 64; ++j) e[j] = p.htab[lane + 64 * j];
+#pragma unroll
+        for (int j = 0; j < kHtabEntries / 64; ++j) {
+            htab[lane + 64 * j] = e[j] & 0x7FFFFFFu;
+            hlen[lane + 64 * j] = (uint8_t)(e[j] >> 27);
+        }
     }
 
     const uint32_t b = c * kChunkMcus + lane;
@@ -491,8 +499,11 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
     // DC predictors for lane 0: the MCU just before this chunk (0 at the start of an image: rst)
     // (a segment that continues an image, flags bit 2, takes them from the last MCU of the block row above
     // its first row)
-    int halo[3] = {0, 0, 0};
-    if (c > 0 || (p.flags & 4u)) {
+    // Only the load is issued here; the DC values are worked out where they are used, after the first
+    // component's pixel loads have been issued too, so that the two memory latencies overlap.
+    const bool need_halo = c > 0 || (p.flags & 4u);
+    uint32_t hR = 0, hG = 0, hB = 0;
+    if (need_halo) {
         int64_t hy = -1, hx = (int64_t)p.mcu_w - 1;
         if (c > 0) {
             const uint32_t hb = c * kChunkMcus - 1;
@@ -500,14 +511,7 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
             hx = hb - (uint32_t)hy * p.mcu_w;
         }
         const uint8_t* hp = img_base + (hy * 8 + (lane >> 3)) * p.stride + hx * 24 + (lane & 7) * 3;
-        const uint32_t R = hp[0], G = hp[1], B = hp[2];
-#pragma unroll
-        for (int comp = 0; comp < 3; ++comp) {
-            const CompCoef cc = comp_coef(comp);
-            int smp = colour<0>(R, G, B, cc.k0, cc.cr, cc.cg, cc.cb);
-            if (comp != 0) smp = WRAP ? (smp & 0xFF) : min(smp, 255);
-            halo[comp] = halo_dc(smp, comp == 0, QUANT ? p.qmul[comp * 64] : 4096, QUANT);
-        }
+        hR = hp[0], hG = hp[1], hB = hp[2];
     }
     __syncthreads();  // htab visible
 
@@ -589,7 +593,12 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
                 for (int i = 0; i < 64; ++i) x[i] = quant(x[i], qm[i]);
             }
             int pred = __shfl_up(x[0], 1);
-            const int h = (comp == 0) ? halo[0] : (comp == 1) ? halo[1] : halo[2];
+            int h = 0;
+            if (need_halo) {
+                int smp = colour<0>(hR, hG, hB, cc.k0, cc.cr, cc.cg, cc.cb);
+                if (comp != 0) smp = WRAP ? (smp & 0xFF) : min(smp, 255);
+                h = halo_dc(smp, comp == 0, QUANT ? p.qmul[comp * 64] : 4096, QUANT);
+            }
             if (lane == 0) pred = h;
             if (n_groups == 1 && !fit)
                 encode_block<false, QUANT>(x, pred, comp == 1 && cb_quirk, htab, hlen, priv, bw);
