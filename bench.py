@@ -197,10 +197,13 @@ def main():
             achieved = alg_bytes_step / launches_per_step / (avg_ms * 1e-3) / 1e9
             traffic = None
             tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            valu_busy = None
             if os.path.exists(tfile):
                 try:
-                    per_frame = json.load(open(tfile)).get("k_encode_chunks_hbm_bytes_per_frame")
+                    pmc = json.load(open(tfile))
+                    per_frame = pmc.get("k_encode_chunks_hbm_bytes_per_frame")
                     traffic = round(per_frame * nf / launches_per_step) if per_frame else None
+                    valu_busy = pmc.get("valu", {}).get("k_encode_chunks_valu_busy")
                 except Exception:
                     traffic = None
             line["roofline"] = {"bound": "hbm", "kernel": "k_encode_chunks", "achieved": round(achieved, 1),
@@ -208,6 +211,8 @@ def main():
                                 "traffic": traffic,
                                 "algorithmic_bytes_per_launch": round(alg_bytes_step / launches_per_step),
                                 "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step}
+            if valu_busy is not None:  # counter pass kept under profiles/: the kernel is issue-bound, not HBM-bound
+                line["roofline"]["valu_busy_from_profile"] = valu_busy
             all_ms = sum(v[1] for v in ktimes.values()) / args.steps
             line["kernel_ms_per_step"] = {k: round(v[1] / args.steps, 4) for k, v in ktimes.items()}
             line["pipeline_hbm_frac"] = round(alg_bytes_step / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
