@@ -201,34 +201,50 @@ __device__ __forceinline__ int pack16(int lo, int hi) {  // low halves of two re
     return (int)__builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u);
 }
 
-// Inputs as pairs p01 = (x0,x1), p23 = (x2,x3), p76 = (x7,x6), p54 = (x5,x4); y[k] = (sum + bias) >> sh.
-__device__ __forceinline__ void dct8p(int p01, int p23, int p76, int p54, int bias0, int bias, int sh, int (&y)[8]) {
+// Inputs as pairs p01 = (x0,x1), p23 = (x2,x3), p76 = (x7,x6), p54 = (x5,x4); a[k] = sum + bias.
+__device__ __forceinline__ void dct8p_acc(int p01, int p23, int p76, int p54, int bias0, int bias, int (&a)[8]) {
     const int s01 = pk_add(p01, p76), s23 = pk_add(p23, p54);  // (s0,s1), (s2,s3)
     const int d01 = pk_sub(p01, p76), d23 = pk_sub(p23, p54);  // (d0,d1), (d2,d3)
     const int e = pk_add_x(s01, s23);                           // (s0+s3, s1+s2)
     const int f = pk_sub_x(s01, s23);                           // (s0-s3, s1-s2)
-    y[0] = dot2(e, cpair(5793, 5793), bias0) >> sh;
-    y[4] = dot2(e, cpair(5793, -5793), bias) >> sh;
-    y[2] = dot2(f, cpair(7568, 3135), bias) >> sh;
-    y[6] = dot2(f, cpair(3135, -7568), bias) >> sh;
-    y[1] = dot2(d23, cpair(4551, 1598), dot2(d01, cpair(8035, 6811), bias)) >> sh;
-    y[3] = dot2(d23, cpair(-8035, -4551), dot2(d01, cpair(6811, -1598), bias)) >> sh;
-    y[5] = dot2(d23, cpair(1598, 6811), dot2(d01, cpair(4551, -8035), bias)) >> sh;
-    y[7] = dot2(d23, cpair(6811, -8035), dot2(d01, cpair(1598, -4551), bias)) >> sh;
+    a[0] = dot2(e, cpair(5793, 5793), bias0);
+    a[4] = dot2(e, cpair(5793, -5793), bias);
+    a[2] = dot2(f, cpair(7568, 3135), bias);
+    a[6] = dot2(f, cpair(3135, -7568), bias);
+    a[1] = dot2(d23, cpair(4551, 1598), dot2(d01, cpair(8035, 6811), bias));
+    a[3] = dot2(d23, cpair(-8035, -4551), dot2(d01, cpair(6811, -1598), bias));
+    a[5] = dot2(d23, cpair(1598, 6811), dot2(d01, cpair(4551, -8035), bias));
+    a[7] = dot2(d23, cpair(6811, -8035), dot2(d01, cpair(1598, -4551), bias));
+}
+// y[k] = (sum + bias) >> sh
+__device__ __forceinline__ void dct8p(int p01, int p23, int p76, int p54, int bias0, int bias, int sh, int (&y)[8]) {
+    dct8p_acc(p01, p23, p76, p54, bias0, bias, y);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) y[k] >>= sh;
 }
 
-// Pass 1 on two consecutive rows of samples (c0: row 2i, c1: row 2i+1, values 0..255) and packing of
-// the results for pass 2: col[k] = (B[lo_row][k], B[hi_row][k]) with lo_row = 2i for the upper half of
-// the block and 2i+1 for the lower half (pass 2 wants the pairs (B0,B1), (B2,B3), (B5,B4), (B7,B6)).
+// (lo >> sh) in the low half, (hi >> sh) in the high half: the second shift writes its 16 result bits
+// straight into the upper half of the first one's register (SDWA), so no separate packing instruction.
+__device__ __forceinline__ int shift_pack(int lo, int hi, int sh) {
+    int r = lo >> sh;
+    asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+        : "+v"(r)
+        : "v"(sh), "v"(hi));
+    return r;
+}
+
+// Pass 1 on two consecutive rows of samples (p0: row 2i, p1: row 2i+1, values 0..255, packed as dct8p_acc
+// wants them) and packing of the results for pass 2: col[k] = (B[lo_row][k], B[hi_row][k]) with lo_row = 2i
+// for the upper half of the block and 2i+1 for the lower half (pass 2 wants the pairs (B0,B1), (B2,B3),
+// (B5,B4), (B7,B6)).
 template <bool LUMA>
-__device__ __forceinline__ void dct_row_pair(const int (&c0)[8], const int (&c1)[8], bool lower_half, int (&col)[8]) {
-    int y0[8], y1[8];
-    dct8p(c0[0] | (c0[1] << 16), c0[2] | (c0[3] << 16), c0[7] | (c0[6] << 16), c0[5] | (c0[4] << 16),
-          DctK<LUMA>::b1 - JPEGENC_DCT_LEVEL_SHIFT, DctK<LUMA>::b1, DctK<LUMA>::sh1, y0);
-    dct8p(c1[0] | (c1[1] << 16), c1[2] | (c1[3] << 16), c1[7] | (c1[6] << 16), c1[5] | (c1[4] << 16),
-          DctK<LUMA>::b1 - JPEGENC_DCT_LEVEL_SHIFT, DctK<LUMA>::b1, DctK<LUMA>::sh1, y1);
+__device__ __forceinline__ void dct_row_pair(const int (&p0)[4], const int (&p1)[4], bool lower_half, int (&col)[8]) {
+    int a0[8], a1[8];
+    dct8p_acc(p0[0], p0[1], p0[2], p0[3], DctK<LUMA>::b1 - JPEGENC_DCT_LEVEL_SHIFT, DctK<LUMA>::b1, a0);
+    dct8p_acc(p1[0], p1[1], p1[2], p1[3], DctK<LUMA>::b1 - JPEGENC_DCT_LEVEL_SHIFT, DctK<LUMA>::b1, a1);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) col[k] = lower_half ? pack16(y1[k], y0[k]) : pack16(y0[k], y1[k]);
+    for (int k = 0; k < 8; ++k)
+        col[k] = lower_half ? shift_pack(a1[k], a0[k], DctK<LUMA>::sh1) : shift_pack(a0[k], a1[k], DctK<LUMA>::sh1);
 }
 
 // Pass 2: column k from its four row pairs -> x[j*8+k], j = vertical frequency.
@@ -407,13 +423,36 @@ __device__ __forceinline__ uint32_t raw_byte(const uint32_t (&raw)[48], int r, i
 // arithmetic shift is the RTL's bit slice.  The rounded value is 0..256; 256 is reachable only by Cb and
 // Cr (pure blue / pure red).  MODE 0: luma, no fix-up needed; MODE 1: chroma as written, the 8-bit
 // rounder wraps 256 to 0 and the clamp is dead code; MODE 2: chroma with the clamp working.
+__device__ __forceinline__ int colour_sum(uint32_t R, uint32_t G, uint32_t B, int k0, int cr, int cg, int cb) {
+    return k0 + __mul24(cr, (int)R) + __mul24(cg, (int)G) + __mul24(cb, (int)B);
+}
 template <int MODE>
 __device__ __forceinline__ int colour(uint32_t R, uint32_t G, uint32_t B, int k0, int cr, int cg, int cb) {
-    const int s = k0 + __mul24(cr, (int)R) + __mul24(cg, (int)G) + __mul24(cb, (int)B);
-    const int v = s >> 14;
+    const int v = colour_sum(R, G, B, k0, cr, cg, cb) >> 14;
     if constexpr (MODE == 0) return v;
     if constexpr (MODE == 1) return v & 0xFF;
     return min(v, 255);
+}
+// Two samples from their sums, packed (lo, hi) for the transform.  The second sample's last instruction
+// writes into the upper half of the first one's register (SDWA): byte 2 of a register whose upper half is
+// zero for MODE 0 (luma never reaches 256) and MODE 1 (the wrap is the byte select), the upper word for
+// the clamp of MODE 2.
+template <int MODE>
+__device__ __forceinline__ int colour_pair(int s_lo, int s_hi) {
+    int r = s_lo >> 14;
+    if constexpr (MODE == 1) r &= 0xFF;
+    if constexpr (MODE == 2) r = min(r, 255);
+    if constexpr (MODE == 2) {
+        const int t = s_hi >> 14;
+        asm("v_min_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+            : "+v"(r)
+            : "v"(255), "v"(t));
+    } else {
+        asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+            : "+v"(r)
+            : "v"(14), "v"(s_hi));
+    }
+    return r;
 }
 
 struct CompCoef {
@@ -426,6 +465,20 @@ __device__ __forceinline__ CompCoef comp_coef(int comp) {
     c.cg = (comp == 0) ? JPEGENC_Y_G : (comp == 1) ? -JPEGENC_CB_G : -JPEGENC_CR_G;
     c.cb = (comp == 0) ? JPEGENC_Y_B : (comp == 1) ? JPEGENC_CB_B : -JPEGENC_CR_B;
     return c;
+}
+
+// The 8 pixels of row r of the MCU as the four pairs (x0,x1), (x2,x3), (x7,x6), (x5,x4) of one component.
+template <int MODE>
+__device__ __forceinline__ void colour_row(const uint32_t (&raw)[48], int r, const CompCoef& cc, int (&p)[4]) {
+    int s[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        s[q] = colour_sum(raw_byte(raw, r, 3 * q), raw_byte(raw, r, 3 * q + 1), raw_byte(raw, r, 3 * q + 2), cc.k0, cc.cr,
+                          cc.cg, cc.cb);
+    p[0] = colour_pair<MODE>(s[0], s[1]);
+    p[1] = colour_pair<MODE>(s[2], s[3]);
+    p[2] = colour_pair<MODE>(s[7], s[6]);
+    p[3] = colour_pair<MODE>(s[5], s[4]);
 }
 
 // quantiser (y_quantizer.sv:58, 74, 106): 11-bit result of (F * (4096/Q) + 2048) >> 12; the 23-bit
@@ -558,15 +611,10 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
                 int pc[4][8];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    int c0[8], c1[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        c0[q] = colour<0>(raw_byte(raw, 2 * i, 3 * q), raw_byte(raw, 2 * i, 3 * q + 1),
-                                          raw_byte(raw, 2 * i, 3 * q + 2), cc.k0, cc.cr, cc.cg, cc.cb);
-                        c1[q] = colour<0>(raw_byte(raw, 2 * i + 1, 3 * q), raw_byte(raw, 2 * i + 1, 3 * q + 1),
-                                          raw_byte(raw, 2 * i + 1, 3 * q + 2), cc.k0, cc.cr, cc.cg, cc.cb);
-                    }
-                    dct_row_pair<true>(c0, c1, i >= 2, pc[i]);
+                    int p0[4], p1[4];
+                    colour_row<0>(raw, 2 * i, cc, p0);
+                    colour_row<0>(raw, 2 * i + 1, cc, p1);
+                    dct_row_pair<true>(p0, p1, i >= 2, pc[i]);
                 }
                 dct_cols_packed<true>(pc, x);
                 asm volatile("; luma dct done" ::: "memory");
@@ -574,15 +622,10 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
                 int pc[4][8];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    int c0[8], c1[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        c0[q] = colour<WRAP ? 1 : 2>(raw_byte(raw, 2 * i, 3 * q), raw_byte(raw, 2 * i, 3 * q + 1),
-                                                     raw_byte(raw, 2 * i, 3 * q + 2), cc.k0, cc.cr, cc.cg, cc.cb);
-                        c1[q] = colour<WRAP ? 1 : 2>(raw_byte(raw, 2 * i + 1, 3 * q), raw_byte(raw, 2 * i + 1, 3 * q + 1),
-                                                     raw_byte(raw, 2 * i + 1, 3 * q + 2), cc.k0, cc.cr, cc.cg, cc.cb);
-                    }
-                    dct_row_pair<false>(c0, c1, i >= 2, pc[i]);
+                    int p0[4], p1[4];
+                    colour_row<WRAP ? 1 : 2>(raw, 2 * i, cc, p0);
+                    colour_row<WRAP ? 1 : 2>(raw, 2 * i + 1, cc, p1);
+                    dct_row_pair<false>(p0, p1, i >= 2, pc[i]);
                 }
                 dct_cols_packed<false>(pc, x);
                 asm volatile("; chroma dct done" ::: "memory");
