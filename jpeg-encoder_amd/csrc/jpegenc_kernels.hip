@@ -470,11 +470,18 @@ __device__ __forceinline__ CompCoef comp_coef(int comp) {
 // The 8 pixels of row r of the MCU as the four pairs (x0,x1), (x2,x3), (x7,x6), (x5,x4) of one component.
 template <int MODE>
 __device__ __forceinline__ void colour_row(const uint32_t (&raw)[48], int r, const CompCoef& cc, int (&p)[4]) {
+    // R and G of a pixel are gathered into the two halves of a register (v_perm over the one or two dwords
+    // they sit in) and multiplied and summed with k0 by one v_dot2_i32_i16; B comes in by a byte-select multiply.
+    const int crg = cpair(cc.cr, cc.cg);
     int s[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
-        s[q] = colour_sum(raw_byte(raw, r, 3 * q), raw_byte(raw, r, 3 * q + 1), raw_byte(raw, r, 3 * q + 2), cc.k0, cc.cr,
-                          cc.cg, cc.cb);
+    for (int q = 0; q < 8; ++q) {
+        const int j = 3 * q, d = j >> 2, b = j & 3;
+        const uint32_t lo = raw[r * 6 + d], hi = raw[r * 6 + (b == 3 ? d + 1 : d)];
+        const uint32_t sel = 0x0C000C00u | (uint32_t)b | ((uint32_t)(b == 3 ? 4 : b + 1) << 16);
+        const int rg = (int)__builtin_amdgcn_perm(hi, lo, sel);
+        s[q] = dot2(rg, crg, cc.k0) + __mul24(cc.cb, (int)raw_byte(raw, r, j + 2));
+    }
     p[0] = colour_pair<MODE>(s[0], s[1]);
     p[1] = colour_pair<MODE>(s[2], s[3]);
     p[2] = colour_pair<MODE>(s[7], s[6]);
