@@ -98,34 +98,7 @@ __device__ constexpr uint8_t kZZ[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 
 // every product and sum below is the same integer the RTL's multiply-accumulate produces
 // (cb_dct.sv:433-439, 467-473 for pass 1, :198-231, :265-281 for pass 2).  `bias0` is added to y_0 and
 // `bias` to y_1..7 so that the rounding "bits above n plus the bit below" becomes one arithmetic shift.
-// All operands fit 24 bits (|x| <= 5792, |T| <= 8035), so the 24-bit multiplier is exact.
 // ------------------------------------------------------------------------------------------------
-// acc + a * coef with the 24-bit multiplier.  Written as one instruction so that each output is a
-// chain of fused multiply-adds: left to itself the compiler materialises all 28 products of a
-// transform first and spills them.
-__device__ __forceinline__ int mad24(int a, int coef, int acc) {
-    int r;
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(coef), "v"(acc));
-    return r;
-}
-
-__device__ __forceinline__ void dct8(int& x0, int& x1, int& x2, int& x3, int& x4, int& x5, int& x6, int& x7,
-                                     int bias0, int bias, int sh) {
-    const int s0 = x0 + x7, s1 = x1 + x6, s2 = x2 + x5, s3 = x3 + x4;
-    const int d0 = x0 - x7, d1 = x1 - x6, d2 = x2 - x5, d3 = x3 - x4;
-    const int e0 = s0 + s3, e1 = s1 + s2, f0 = s0 - s3, f1 = s1 - s2;
-    const int y0 = mad24(e0 + e1, 5793, bias0);
-    const int y4 = mad24(e0 - e1, 5793, bias);
-    const int y2 = mad24(f1, 3135, mad24(f0, 7568, bias));
-    const int y6 = mad24(f1, -7568, mad24(f0, 3135, bias));
-    const int y1 = mad24(d3, 1598, mad24(d2, 4551, mad24(d1, 6811, mad24(d0, 8035, bias))));
-    const int y3 = mad24(d3, -4551, mad24(d2, -8035, mad24(d1, -1598, mad24(d0, 6811, bias))));
-    const int y5 = mad24(d3, 6811, mad24(d2, 1598, mad24(d1, -8035, mad24(d0, 4551, bias))));
-    const int y7 = mad24(d3, -8035, mad24(d2, 6811, mad24(d1, -4551, mad24(d0, 1598, bias))));
-    x0 = y0 >> sh; x1 = y1 >> sh; x2 = y2 >> sh; x3 = y3 >> sh;
-    x4 = y4 >> sh; x5 = y5 >> sh; x6 = y6 >> sh; x7 = y7 >> sh;
-}
-
 __device__ __forceinline__ int sext11(int v) { return (v << 21) >> 21; }
 
 // 2-D transform of one component block held in registers.  In: x[r*8+c] samples 0..255.
@@ -145,28 +118,14 @@ struct DctK {
     static constexpr int b2 = 1 << (sh2 - 1);
 };
 
-// pass 1 on one row of samples (in place): x[r][c] -> B[r][k]
-template <bool LUMA>
-__device__ __forceinline__ void dct_row(int (&x)[64], int r) {
-    dct8(x[r * 8 + 0], x[r * 8 + 1], x[r * 8 + 2], x[r * 8 + 3], x[r * 8 + 4], x[r * 8 + 5], x[r * 8 + 6],
-         x[r * 8 + 7], DctK<LUMA>::b1 - JPEGENC_DCT_LEVEL_SHIFT, DctK<LUMA>::b1, DctK<LUMA>::sh1);
-}
+// The 11-bit output ports of pass 2 (cb_dct.sv:20-35) cannot wrap for 8-bit samples: DC lies in
+// [-1024, 1016] and |AC| <= 1021 (|Z| <= 1448 * 46344 for luma, 363 * 46344 for chroma, before the final
+// shift).
 
-// pass 2 on all columns (in place): B[r][k] -> F[j][k].  The 11-bit output ports (cb_dct.sv:20-35)
-// cannot wrap for 8-bit samples: DC lies in [-1024, 1016] and |AC| <= 1021 (|Z| <= 1448 * 46344 for
-// luma, 363 * 46344 for chroma, before the final shift).
-template <bool LUMA>
-__device__ __forceinline__ void dct_cols(int (&x)[64]) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-        dct8(x[0 * 8 + k], x[1 * 8 + k], x[2 * 8 + k], x[3 * 8 + k], x[4 * 8 + k], x[5 * 8 + k], x[6 * 8 + k],
-             x[7 * 8 + k], DctK<LUMA>::b2, DctK<LUMA>::b2, DctK<LUMA>::sh2);
-}
-
-// ---- packed form of the same transform ------------------------------------------------------------
+// ---- the transform on packed operands ------------------------------------------------------------
 // Two 16-bit values per register: v_pk_add/sub_i16 fold two pairs at once and v_dot2_i32_i16 does two
 // multiply-adds per instruction, exactly (16 x 16 -> 32-bit products, 32-bit accumulate; every operand
-// fits 16 bits: |fold| <= 5792, |T| <= 8035).  Same integers as dct8(), 18 instructions instead of 36.
+// fits 16 bits: |fold| <= 5792, |T| <= 8035): 18 instructions per 8-point transform plus the shifts.
 __device__ __forceinline__ int pk_add(int a, int b) {
     int r;
     asm("v_pk_add_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -197,9 +156,6 @@ __device__ __forceinline__ int dot2(int a, int c, int acc) {
     return r;
 }
 __host__ __device__ constexpr int cpair(int lo, int hi) { return (int)(((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16)); }
-__device__ __forceinline__ int pack16(int lo, int hi) {  // low halves of two registers
-    return (int)__builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u);
-}
 
 // Inputs as pairs p01 = (x0,x1), p23 = (x2,x3), p76 = (x7,x6), p54 = (x5,x4); a[k] = sum + bias.
 __device__ __forceinline__ void dct8p_acc(int p01, int p23, int p76, int p54, int bias0, int bias, int (&a)[8]) {
@@ -559,11 +515,8 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
     // DC predictors for lane 0: the MCU just before this chunk (0 at the start of an image: rst)
     // (a segment that continues an image, flags bit 2, takes them from the last MCU of the block row above
     // its first row)
-    // Only the load is issued here; the DC values are worked out where they are used, after the first
-    // component's pixel loads have been issued too, so that the two memory latencies overlap.
-    const bool need_halo = c > 0 || (p.flags & 4u);
-    uint32_t hR = 0, hG = 0, hB = 0;
-    if (need_halo) {
+    int halo[3] = {0, 0, 0};
+    if (c > 0 || (p.flags & 4u)) {
         int64_t hy = -1, hx = (int64_t)p.mcu_w - 1;
         if (c > 0) {
             const uint32_t hb = c * kChunkMcus - 1;
@@ -571,7 +524,14 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
             hx = hb - (uint32_t)hy * p.mcu_w;
         }
         const uint8_t* hp = img_base + (hy * 8 + (lane >> 3)) * p.stride + hx * 24 + (lane & 7) * 3;
-        hR = hp[0], hG = hp[1], hB = hp[2];
+        const uint32_t R = hp[0], G = hp[1], B = hp[2];
+#pragma unroll
+        for (int comp = 0; comp < 3; ++comp) {
+            const CompCoef cc = comp_coef(comp);
+            int smp = colour<0>(R, G, B, cc.k0, cc.cr, cc.cg, cc.cb);
+            if (comp != 0) smp = WRAP ? (smp & 0xFF) : min(smp, 255);
+            halo[comp] = halo_dc(smp, comp == 0, QUANT ? p.qmul[comp * 64] : 4096, QUANT);
+        }
     }
     __syncthreads();  // htab visible
 
@@ -643,12 +603,7 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
                 for (int i = 0; i < 64; ++i) x[i] = quant(x[i], qm[i]);
             }
             int pred = __shfl_up(x[0], 1);
-            int h = 0;
-            if (need_halo) {
-                int smp = colour<0>(hR, hG, hB, cc.k0, cc.cr, cc.cg, cc.cb);
-                if (comp != 0) smp = WRAP ? (smp & 0xFF) : min(smp, 255);
-                h = halo_dc(smp, comp == 0, QUANT ? p.qmul[comp * 64] : 4096, QUANT);
-            }
+            const int h = (comp == 0) ? halo[0] : (comp == 1) ? halo[1] : halo[2];
             if (lane == 0) pred = h;
             if (n_groups == 1 && !fit)
                 encode_block<false, QUANT>(x, pred, comp == 1 && cb_quirk, htab, hlen, priv, bw);
