@@ -481,9 +481,11 @@ constexpr int kPrivWords = 64 * kRegionWords + 120;
 static_assert(63 * kRegionWords + kMaxMcuWords <= kPrivWords, "tier-1 overrun of the last lane");
 static_assert(4 * kRegionWords - 2 >= kMaxMcuWords, "tier 3 must hold the worst-case MCU");
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 template <int ALIGN, bool QUANT, bool WRAP>
 __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
-    __shared__ uint32_t priv[kPrivWords];
+    __shared__ __attribute__((aligned(16))) uint32_t priv[kPrivWords];
     __shared__ uint32_t htab[kHtabEntries];  // code << size
     __shared__ uint8_t hlen[kHtabEntries];   // code length + size
     const int lane = threadIdx.x;
@@ -657,7 +659,14 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
 #pragma unroll
             for (int t = 0; t < kOwnWords; ++t) own[t] = priv[base + 1 + t];
             wave_sync();
-            for (uint32_t i = lane; i < ((gtotal + 31u) >> 5); i += 64) priv[i] = 0u;
+            // (The four-word forms here and in the slot copy below are left out of the quantising variants:
+            // their streams are short, and at the register limit the allocator then spills more.)
+            if constexpr (QUANT) {
+                for (uint32_t i = lane; i < ((gtotal + 31u) >> 5); i += 64) priv[i] = 0u;
+            } else {
+                for (uint32_t i = lane; i < ((gtotal + 127u) >> 7); i += 64)  // four words per lane and step
+                    reinterpret_cast<uint4*>(priv)[i] = make_uint4(0u, 0u, 0u, 0u);
+            }
             wave_sync();
 #pragma unroll
             for (int t0 = 0; t0 < kOwnWords; t0 += 8) {
@@ -714,7 +723,16 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
             const uint32_t s = chunk_total & 31u, d0 = chunk_total >> 5;
             const uint32_t nw = (gtotal + 31u) >> 5;
             const uint32_t nd = (s + gtotal + 31u) >> 5;
-            for (uint32_t t = lane; t < nd; t += 64) {
+            // The chunk's only group (first and fit tiers) starts the slot: whole groups of four words go out
+            // as they are, four per lane and step; the general loop below is left with the last 0 to 3 words.
+            uint32_t t_first = lane;
+            if (!QUANT && n_groups == 1) {
+                const uint32_t nq = nd >> 2;
+                for (uint32_t q = lane; q < nq; q += 64)
+                    __builtin_nontemporal_store(reinterpret_cast<const u32x4*>(priv)[q], reinterpret_cast<u32x4*>(slot) + q);
+                t_first = 4u * nq + lane;
+            }
+            for (uint32_t t = t_first; t < nd; t += 64) {
                 const uint32_t lo = (t < nw) ? priv[t] : 0u;
                 const uint32_t hi = (t >= 1 && t - 1 < nw) ? priv[t - 1] : 0u;
                 uint32_t w = s ? ((hi << (32u - s)) | (lo >> s)) : lo;
