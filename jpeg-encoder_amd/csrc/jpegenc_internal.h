@@ -36,6 +36,7 @@ struct EncodeParams {
     uint32_t mcu_w;        // MCUs per block row (w / 8)
     uint32_t n_mcu;        // MCUs per image
     uint32_t cpi;          // chunks per image = ceil(n_mcu / 64)
+    uint32_t n_images;     // images of this launch (set by launch_encode)
     uint32_t flags;        // bit 0: rgb wrap quirk, bit 1: cb 6'd64 quirk, bit 2: the images continue a
                            // stream: the DC predictors of their first MCU come from the block row above
     uint32_t* slots;       // [n_images * cpi][kSlotWords]

@@ -32,23 +32,6 @@ namespace jpegenc {
 // ------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, int lane, uint32_t* total) {
-    uint32_t x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t y = __shfl_up(x, d);
-        if (lane >= d) x += y;
-    }
-    *total = __shfl(x, 63);
-    return x - v;
-}
-
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d));
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-}
-
 // Orders one wave's LDS traffic for a single-wave workgroup: the compiler may not move LDS accesses
 // across it, and the hardware serves a wave's LDS instructions in order.
 __device__ __forceinline__ void wave_sync() {
@@ -69,6 +52,34 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
     x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
     x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
     return (uint32_t)x;
+}
+
+__device__ __forceinline__ uint32_t wave_excl_scan_u32(uint32_t v, uint32_t* total) {
+    const uint32_t x = wave_incl_scan_dpp(v);
+    *total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+    return x - v;
+}
+
+// Maximum over the wave, the same way (0 is the identity for the lanes without a source).
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    int x = (int)v;
+    x = (int)max((uint32_t)x, (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false));
+    x = (int)max((uint32_t)x, (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false));
+    x = (int)max((uint32_t)x, (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false));
+    x = (int)max((uint32_t)x, (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false));
+    x = (int)max((uint32_t)x, (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false));
+    x = (int)max((uint32_t)x, (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false));
+    return (uint32_t)__builtin_amdgcn_readlane(x, 63);
+}
+
+// Value of lane (lane ^ M).  The library shuffles clamp their lane index with a compare and a v_cndmask
+// each (about 20 cycles of the vector ALU per wave); ds_swizzle takes the pattern as an immediate.
+template <int M>
+__device__ __forceinline__ int xor_lane(int v, int lane) {
+    if constexpr (M < 32)
+        return __builtin_amdgcn_ds_swizzle(v, 0x1F | (M << 10));  // bit mode: and 0x1F, or 0, xor M
+    else
+        return __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, v);
 }
 
 // Three-input logic in one v_bitop3_b32 with register operands only.  On gfx950 this instruction, like
@@ -227,8 +238,9 @@ __device__ __forceinline__ void dct_cols_packed(const int (&pc)[4][8], int (&x)[
 struct BitWriter {
     uint64_t win;   // the last 64 bits appended (older bits shift out)
     uint32_t T;     // bit position: priv word index of the last completed word * 32 + pending bits
-    uint32_t dump;  // GUARD only: byte address of the region's word 0
-    uint32_t wlim;  // GUARD only: first byte address the lane may not store to (0: store nothing)
+    uint32_t wlim;  // GUARD only: byte address that takes every store beyond it (one minimum, no select):
+                    // the word behind the string's room, rewritten by the flush; the region's word 0 for a
+                    // lane that only counts its bits
 };
 
 // Branch-free append of (bits,len), len <= 26 (one append completes at most one word).  GUARD = false
@@ -243,7 +255,7 @@ __device__ __forceinline__ void bw_emit(BitWriter& s, uint32_t bits, uint32_t am
     s.win = (s.win & 0xFFFFFFFF00000000ull) | lo;
     const uint32_t word = __builtin_amdgcn_alignbit((uint32_t)(s.win >> 32), lo, s.T);
     uint32_t at = (s.T >> 3) & ~3u;
-    if constexpr (GUARD) at = (at < s.wlim) ? at : s.dump;
+    if constexpr (GUARD) at = min(at, s.wlim);
     *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(priv) + at) = word;
 }
 
@@ -450,16 +462,16 @@ __device__ __forceinline__ int quant(int f, int qm) { return sext11((__mul24(f, 
 
 // DC coefficient of one component of the MCU *before* this chunk, computed by the whole wave (lane =
 // pixel): needed as the DC predictor of lane 0.  Same arithmetic as dct8x8 restricted to k = j = 0.
-__device__ __forceinline__ int halo_dc(int sample, bool luma, int qm0, bool do_quant) {
+__device__ __forceinline__ int halo_dc(int sample, bool luma, int qm0, bool do_quant, int lane) {
     int s = sample;
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    s += __shfl_xor(s, 4);  // row sum, identical in the 8 lanes of a row
+    s += xor_lane<1>(s, lane);
+    s += xor_lane<2>(s, lane);
+    s += xor_lane<4>(s, lane);  // row sum, identical in the 8 lanes of a row
     const int sh1 = luma ? 12 : 14, sh2 = luma ? 16 : 14;
     int b = (__mul24(5793, s) - JPEGENC_DCT_LEVEL_SHIFT + (1 << (sh1 - 1))) >> sh1;
-    b += __shfl_xor(b, 8);
-    b += __shfl_xor(b, 16);
-    b += __shfl_xor(b, 32);  // sum over the 8 rows
+    b += xor_lane<8>(b, lane);
+    b += xor_lane<16>(b, lane);
+    b += xor_lane<32>(b, lane);  // sum over the 8 rows
     int f = sext11((__mul24(5793, b) + (1 << (sh2 - 1))) >> sh2);
     if (do_quant) f = quant(f, qm0);
     return f;
@@ -489,9 +501,11 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
     __shared__ uint32_t htab[kHtabEntries];  // code << size
     __shared__ uint8_t hlen[kHtabEntries];   // code length + size
     const int lane = threadIdx.x;
-    const uint32_t gid = blockIdx.x;
-    const uint32_t img = gid / p.cpi;
-    const uint32_t c = gid - img * p.cpi;
+    // grid: x = chunk of the image, y and z = image (no division)
+    const uint32_t c = blockIdx.x;
+    const uint32_t img = blockIdx.z * 65535u + blockIdx.y;
+    if (img >= p.n_images) return;
+    const uint32_t gid = img * p.cpi + c;
     const bool cb_quirk = (p.flags & 2u) != 0;
 
     {
@@ -506,11 +520,25 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
         }
     }
 
-    const uint32_t b = c * kChunkMcus + lane;
+    // MCU coordinates: one division for the chunk's first MCU (wave-uniform); a lane's own follow from its
+    // offset with at most one step to the next block row when the image is at least 64 MCUs wide.  Lanes
+    // behind the image's last MCU read that last MCU.
+    const uint32_t b0 = c * kChunkMcus;
+    const uint32_t by0 = b0 / p.mcu_w, bx0 = b0 - by0 * p.mcu_w;
+    const uint32_t b = b0 + lane;
     const bool valid = b < p.n_mcu;
-    const uint32_t bb = valid ? b : (p.n_mcu - 1);
-    const uint32_t by = bb / p.mcu_w;
-    const uint32_t bx = bb - by * p.mcu_w;
+    const uint32_t off = min((uint32_t)lane, p.n_mcu - 1u - b0);
+    uint32_t by, bx;
+    if (p.mcu_w >= (uint32_t)kChunkMcus) {
+        const uint32_t x = bx0 + off;
+        const uint32_t wrap = (uint32_t)((int32_t)(p.mcu_w - 1u - x) >> 31);  // all ones when x >= mcu_w
+        by = by0 - wrap;
+        bx = x - (wrap & p.mcu_w);
+    } else {
+        const uint32_t bb = b0 + off;
+        by = bb / p.mcu_w;
+        bx = bb - by * p.mcu_w;
+    }
     const uint8_t* img_base = p.rgb + (int64_t)img * p.image_stride;
     const uint8_t* src = img_base + (int64_t)by * 8 * p.stride + (int64_t)bx * 24;
 
@@ -519,12 +547,9 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
     // its first row)
     int halo[3] = {0, 0, 0};
     if (c > 0 || (p.flags & 4u)) {
-        int64_t hy = -1, hx = (int64_t)p.mcu_w - 1;
-        if (c > 0) {
-            const uint32_t hb = c * kChunkMcus - 1;
-            hy = hb / p.mcu_w;
-            hx = hb - (uint32_t)hy * p.mcu_w;
-        }
+        // the MCU before the chunk's first one: left of it, or the last one of the block row above
+        const int64_t hy = bx0 ? (int64_t)by0 : (int64_t)by0 - 1;
+        const int64_t hx = bx0 ? (int64_t)bx0 - 1 : (int64_t)p.mcu_w - 1;
         const uint8_t* hp = img_base + (hy * 8 + (lane >> 3)) * p.stride + hx * 24 + (lane & 7) * 3;
         const uint32_t R = hp[0], G = hp[1], B = hp[2];
 #pragma unroll
@@ -532,7 +557,7 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
             const CompCoef cc = comp_coef(comp);
             int smp = colour<0>(R, G, B, cc.k0, cc.cr, cc.cg, cc.cb);
             if (comp != 0) smp = WRAP ? (smp & 0xFF) : min(smp, 255);
-            halo[comp] = halo_dc(smp, comp == 0, QUANT ? p.qmul[comp * 64] : 4096, QUANT);
+            halo[comp] = halo_dc(smp, comp == 0, QUANT ? p.qmul[comp * 64] : 4096, QUANT, lane);
         }
     }
     __syncthreads();  // htab visible
@@ -550,10 +575,11 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
     bool fit = false;
     uint32_t fit_base = 0, fit_cap = 0;
     for (int g = 0; g < n_groups; ++g) {
-        const int lanes_per_group = 64 / n_groups;
-        const uint32_t stride = (uint32_t)kRegionWords * (uint32_t)n_groups;
+        const int lg = n_groups >> 1;  // log2 of 1, 2, 4
+        const int lanes_per_group = 64 >> lg;
+        const uint32_t stride = (uint32_t)kRegionWords << lg;
         const uint32_t cap = fit ? fit_cap : stride - 2u;
-        const bool active = valid && (lane / lanes_per_group) == g;
+        const bool active = valid && (lane >> (6 - lg)) == g;
         const uint32_t base = fit ? fit_base : (uint32_t)(lane & (lanes_per_group - 1)) * stride;
         // region: word 0 takes the stores of the bit writer that are not meant to land, words [1, 1+cap)
         // the string, one more word the zero behind a full string; lanes of other groups count their
@@ -561,8 +587,7 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
         BitWriter bw;
         bw.win = 0;
         bw.T = base * 32u;
-        bw.dump = base * 4u;
-        bw.wlim = active ? (base + 1u + cap) * 4u : 0u;
+        bw.wlim = active ? (base + 1u + cap) * 4u : base * 4u;
 
 #pragma unroll 1
         for (int comp = 0; comp < 3; ++comp) {
@@ -604,9 +629,9 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
 #pragma unroll
                 for (int i = 0; i < 64; ++i) x[i] = quant(x[i], qm[i]);
             }
-            int pred = __shfl_up(x[0], 1);
             const int h = (comp == 0) ? halo[0] : (comp == 1) ? halo[1] : halo[2];
-            if (lane == 0) pred = h;
+            // DC of the lane before; lane 0 has no source and keeps h (wave_shr:1)
+            const int pred = __builtin_amdgcn_update_dpp(h, x[0], 0x138, 0xF, 0xF, false);
             if (n_groups == 1 && !fit)
                 encode_block<false, QUANT>(x, pred, comp == 1 && cb_quirk, htab, hlen, priv, bw);
             else
@@ -624,7 +649,7 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
             // words per lane: the unread word 0, the string, the zero word behind it
             const uint32_t need = ((Lall + 31u) >> 5) + 2u;
             uint32_t need_total;
-            const uint32_t need_off = wave_excl_scan_u32(need, lane, &need_total);
+            const uint32_t need_off = wave_excl_scan_u32(need, &need_total);
             if (need_total <= 64u * kRegionWords) {
                 fit = true;
                 fit_base = need_off;
@@ -645,7 +670,7 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
         // with its predecessor's last word travel in `tailw` (wave-uniform).  In place is safe because a
         // string never moves to a higher address and all reads of a step precede its writes.
         uint32_t gtotal;
-        const uint32_t off = wave_excl_scan_u32(L, lane, &gtotal);
+        const uint32_t off = wave_excl_scan_u32(L, &gtotal);
         if (n_groups == 1 && !fit) {
             // First tier, every lane at once: each lane takes its whole string (at most kOwnWords words,
             // the last one zero) into registers, the destination range is cleared, and every lane ORs
@@ -735,7 +760,7 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
             for (uint32_t t = t_first; t < nd; t += 64) {
                 const uint32_t lo = (t < nw) ? priv[t] : 0u;
                 const uint32_t hi = (t >= 1 && t - 1 < nw) ? priv[t - 1] : 0u;
-                uint32_t w = s ? ((hi << (32u - s)) | (lo >> s)) : lo;
+                uint32_t w = __builtin_amdgcn_alignbit(hi, lo, s);
                 if (t == 0) w |= carry;
                 __builtin_nontemporal_store(w, &slot[d0 + t]);  // streamed: keeps the pixels in L2 for the next component
             }
@@ -1157,25 +1182,32 @@ hipError_t launch_pad_edges(const uint8_t* src, int64_t stride, int64_t image_st
 // launchers
 // ------------------------------------------------------------------------------------------------
 template <int ALIGN, bool QUANT>
-static hipError_t launch_encode_b(const EncodeParams& p, uint32_t grid, hipStream_t s) {
+static hipError_t launch_encode_b(const EncodeParams& p, dim3 grid, hipStream_t s) {
     if (p.flags & 1u)
-        hipLaunchKernelGGL((k_encode_chunks<ALIGN, QUANT, true>), dim3(grid), dim3(64), 0, s, p);
+        hipLaunchKernelGGL((k_encode_chunks<ALIGN, QUANT, true>), grid, dim3(64), 0, s, p);
     else
-        hipLaunchKernelGGL((k_encode_chunks<ALIGN, QUANT, false>), dim3(grid), dim3(64), 0, s, p);
+        hipLaunchKernelGGL((k_encode_chunks<ALIGN, QUANT, false>), grid, dim3(64), 0, s, p);
     return hipGetLastError();
 }
 
 template <int ALIGN>
-static hipError_t launch_encode_a(const EncodeParams& p, uint32_t grid, hipStream_t s) {
+static hipError_t launch_encode_a(const EncodeParams& p, dim3 grid, hipStream_t s) {
     return p.qmul ? launch_encode_b<ALIGN, true>(p, grid, s) : launch_encode_b<ALIGN, false>(p, grid, s);
 }
 
-hipError_t launch_encode(const EncodeParams& p, uint32_t n_images, int align, hipStream_t s) {
-    const uint64_t grid = (uint64_t)n_images * p.cpi;
-    if (grid == 0 || grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    if (align >= 8) return launch_encode_a<8>(p, (uint32_t)grid, s);
-    if (align >= 4) return launch_encode_a<4>(p, (uint32_t)grid, s);
-    return launch_encode_a<1>(p, (uint32_t)grid, s);
+hipError_t launch_encode(const EncodeParams& p_in, uint32_t n_images, int align, hipStream_t s) {
+    EncodeParams p = p_in;
+    p.n_images = n_images;
+    const uint64_t chunks = (uint64_t)n_images * p.cpi;
+    if (chunks == 0 || chunks > 0x7FFFFFFFull) return hipErrorInvalidValue;  // chunk ids are 31-bit
+    // x = chunk, y and z = image (the grid's second and third dimensions end at 65535)
+    const uint32_t ny = n_images < 65535u ? n_images : 65535u;
+    const uint32_t nz = (n_images + 65534u) / 65535u;
+    if (nz > 65535u) return hipErrorInvalidValue;
+    const dim3 grid(p.cpi, ny, nz);
+    if (align >= 8) return launch_encode_a<8>(p, grid, s);
+    if (align >= 4) return launch_encode_a<4>(p, grid, s);
+    return launch_encode_a<1>(p, grid, s);
 }
 
 hipError_t launch_scan(const ScanParams& p, uint32_t n_images, hipStream_t s) {
