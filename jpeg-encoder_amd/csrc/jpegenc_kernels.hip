@@ -349,8 +349,11 @@ __device__ __forceinline__ void encode_block(const int (&blk)[64], int dc_pred, 
     {
         const int v = blk[63];
         const int t = amp_src(v);
-        const uint32_t size = mag_bits(lead_bits(t));
-        const uint32_t at = (v != 0) ? (r5 | size) : (uint32_t)kHtabEob;
+        const int lead = lead_bits(t);
+        const uint32_t size = mag_bits(lead);
+        // lead is -1 for a zero: its sign as a mask picks the EOB entry
+        const uint32_t zmask = (uint32_t)(lead >> 31);
+        const uint32_t at = ((r5 | size) & ~zmask) | ((uint32_t)kHtabEob & zmask);
         bw_emit<GUARD>(bw, htab[at], amp_bits(t, size), hlen[at], priv);
     }
 }
@@ -557,7 +560,9 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
             const CompCoef cc = comp_coef(comp);
             int smp = colour<0>(R, G, B, cc.k0, cc.cr, cc.cg, cc.cb);
             if (comp != 0) smp = WRAP ? (smp & 0xFF) : min(smp, 255);
-            halo[comp] = halo_dc(smp, comp == 0, QUANT ? p.qmul[comp * 64] : 4096, QUANT, lane);
+            // the same value in every lane: kept in scalar registers, so that picking one per component is
+            // scalar work too
+            halo[comp] = __builtin_amdgcn_readfirstlane(halo_dc(smp, comp == 0, QUANT ? p.qmul[comp * 64] : 4096, QUANT, lane));
         }
     }
     __syncthreads();  // htab visible
