@@ -76,9 +76,12 @@ def test_config1_64x64_through_the_port_protocol(enc):
     assert len(words) == 0 and res.n_full_words == 0 and res.tail_bits == 0
 
 
-@pytest.mark.parametrize("hw", [(8, 8), (8, 16), (16, 8), (24, 40), (8, 512), (8, 520), (72, 72), (128, 8), (200, 328)])
+@pytest.mark.parametrize("hw", [(8, 8), (8, 16), (16, 8), (24, 40), (8, 512), (8, 520), (72, 72), (128, 8), (200, 328),
+                                (24, 512), (40, 520), (16, 1016), (24, 504)])
 def test_ragged_sizes_random(enc, hw):
-    # covers: a single MCU, partial chunks, chunks wrapping over block rows, one-MCU-wide images
+    # covers: a single MCU, partial chunks, chunks wrapping over block rows, one-MCU-wide images, and block
+    # rows of exactly 64, just over 64, 127 and 63 MCUs (the kernel derives a lane's MCU coordinates from the
+    # chunk's first MCU with one step to the next block row when a row has at least 64 MCUs)
     h, w = hw
     rgb = np.random.default_rng(h * 1000 + w).integers(0, 256, (h, w, 3), dtype=np.uint8)
     words, res = enc.encode(rgb)
@@ -97,6 +100,16 @@ def test_tiny_last_chunk_shares_its_word(enc):
     words, res = enc.encode_batch(np.stack([big, big[::-1].copy()]))
     for i, img in enumerate((big, big[::-1])):
         assert_same(words[i], res[i], np.ascontiguousarray(img))
+
+
+def test_more_images_than_one_grid_dimension_holds(enc):
+    """The encode kernel's grid carries the image index in y and z (65535 each): 65 540 one-MCU images."""
+    rng = np.random.default_rng(65540)
+    imgs = rng.integers(0, 256, (65540, 8, 8, 3), dtype=np.uint8)
+    words, res = enc.encode_batch(imgs)
+    assert len(words) == len(imgs) and all(int(r["status"]) == 0 for r in res)
+    for i in [0, 1, 65533, 65534, 65535, 65536, 65539] + rng.integers(0, 65540, 24).tolist():
+        assert_same(words[i], res[i], imgs[i])
 
 
 def test_natural_and_noise_1080p(enc):

@@ -4,7 +4,7 @@
 tag=${1:-quick}
 export TMPDIR=/tmp
 timeout -k 10 300 python -u -m pytest tests/test_gpu_parity.py -x -q --timeout 200 --timeout-method thread \
-  -k "config1 or ragged or natural_and_noise or extreme or quirk or batch or bands or tiny" > gpurun_out/${tag}_tests.log 2>&1
+  -k "config1 or ragged or natural_and_noise or extreme or quirk or batch or bands or tiny or grid" > gpurun_out/${tag}_tests.log 2>&1
 rc=$?
 tail -3 gpurun_out/${tag}_tests.log
 if [ $rc -ne 0 ]; then echo "TESTS FAILED rc=$rc"; exit $rc; fi
