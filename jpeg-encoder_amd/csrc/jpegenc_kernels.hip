@@ -361,8 +361,47 @@ __device__ __forceinline__ void encode_block(const int (&blk)[64], int dc_pred, 
 // ------------------------------------------------------------------------------------------------
 // pixel loads: 8 rows x 24 bytes of one MCU into 48 dwords (row r -> raw[6r..6r+5])
 // ------------------------------------------------------------------------------------------------
-template <int ALIGN>
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int ALIGN, bool LAST = false>
 __device__ __forceinline__ void load_mcu(const uint8_t* src, int64_t stride, uint32_t (&raw)[48]) {
+    if constexpr (ALIGN == 8 && LAST) {
+        // The MCU's last fetch, streamed (nt): its lines may leave the L2 before those that other waves still
+        // need.  Written as one asm block because the compiler folds a non-temporal load into the identical
+        // plain one of the other components; the block waits for all its loads itself.
+        const uint8_t* r0 = src;
+        const uint8_t* r1 = src + stride;
+        const uint8_t* r2 = src + 2 * stride;
+        const uint8_t* r3 = src + 3 * stride;
+        const uint8_t* r4 = src + 4 * stride;
+        const uint8_t* r5 = src + 5 * stride;
+        const uint8_t* r6 = src + 6 * stride;
+        const uint8_t* r7 = src + 7 * stride;
+        u32x4 a0, a1, a2, a3, a4, a5, a6, a7;
+        u32x2 b0, b1, b2, b3, b4, b5, b6, b7;
+        asm volatile(
+            "global_load_dwordx4 %0, %16, off nt\n\tglobal_load_dwordx2 %8, %16, off offset:16 nt\n\t"
+            "global_load_dwordx4 %1, %17, off nt\n\tglobal_load_dwordx2 %9, %17, off offset:16 nt\n\t"
+            "global_load_dwordx4 %2, %18, off nt\n\tglobal_load_dwordx2 %10, %18, off offset:16 nt\n\t"
+            "global_load_dwordx4 %3, %19, off nt\n\tglobal_load_dwordx2 %11, %19, off offset:16 nt\n\t"
+            "global_load_dwordx4 %4, %20, off nt\n\tglobal_load_dwordx2 %12, %20, off offset:16 nt\n\t"
+            "global_load_dwordx4 %5, %21, off nt\n\tglobal_load_dwordx2 %13, %21, off offset:16 nt\n\t"
+            "global_load_dwordx4 %6, %22, off nt\n\tglobal_load_dwordx2 %14, %22, off offset:16 nt\n\t"
+            "global_load_dwordx4 %7, %23, off nt\n\tglobal_load_dwordx2 %15, %23, off offset:16 nt\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6), "=&v"(a7),
+              "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(b4), "=&v"(b5), "=&v"(b6), "=&v"(b7)
+            : "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(r4), "v"(r5), "v"(r6), "v"(r7)
+            : "memory");
+        const u32x4 a[8] = {a0, a1, a2, a3, a4, a5, a6, a7};
+        const u32x2 b[8] = {b0, b1, b2, b3, b4, b5, b6, b7};
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            raw[r * 6 + 0] = a[r].x; raw[r * 6 + 1] = a[r].y; raw[r * 6 + 2] = a[r].z;
+            raw[r * 6 + 3] = a[r].w; raw[r * 6 + 4] = b[r].x; raw[r * 6 + 5] = b[r].y;
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const uint8_t* row = src + (int64_t)r * stride;
@@ -496,7 +535,6 @@ constexpr int kPrivWords = 64 * kRegionWords + 120;
 static_assert(63 * kRegionWords + kMaxMcuWords <= kPrivWords, "tier-1 overrun of the last lane");
 static_assert(4 * kRegionWords - 2 >= kMaxMcuWords, "tier 3 must hold the worst-case MCU");
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <int ALIGN, bool QUANT, bool WRAP>
 __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
@@ -602,7 +640,10 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
             // registers across the components spills at the register budget of three waves per SIMD,
             // and the scratch traffic then exceeds the saved fetches (measured).
             uint32_t raw[48];
-            load_mcu<ALIGN>(src, p.stride, raw);
+            if (comp == 2)
+                load_mcu<ALIGN, true>(src, p.stride, raw);  // the last fetch of these pixels
+            else
+                load_mcu<ALIGN>(src, p.stride, raw);
             // Two separately compiled bodies (shifts are immediates).  The differing asm comments keep
             // the optimiser from folding them back into one body with run-time shift counts.  Each row
             // is converted and transformed before the next one is touched, so the raw pixels die early.
