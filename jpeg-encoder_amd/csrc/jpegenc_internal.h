@@ -54,7 +54,7 @@ struct ScanParams {
 struct StuffParams {
     const uint32_t* slots;
     const uint32_t* chunk_bits;
-    const uint64_t* bit_off;  // exclusive prefix of chunk_bits per image
+    uint64_t* bit_off;        // exclusive prefix of chunk_bits per image (written by the count pass when inline_scan)
     uint32_t* chunk_ff;       // count pass: number of 0xFF bytes owned by the chunk
     const uint64_t* ff_off;   // write pass: exclusive prefix of chunk_ff per image
     uint32_t* words_out;      // first image of this launch
@@ -73,6 +73,10 @@ struct StuffParams {
     // How many 1 KB steps of a chunk the stuffing kernels request before they know its length: 5 (all of a
     // photographic chunk at the all-ones tables, 4.4 KB) or 1 (quantised content); selects the kernel variant.
     uint32_t spec_depth;
+    // Small launches (a frame or a few): no k_scan launches; every chunk's wave sums the counts of its image's
+    // earlier chunks itself (k_stuff_count leaves the bit offsets in bit_off for k_stuff_write).  Needs
+    // cpi * 318 720 bits < 2^32.
+    uint32_t inline_scan;
 };
 
 // Launchers (defined in jpegenc_kernels.hip).  align = 8, 4 or 1: guaranteed alignment of every

@@ -889,6 +889,14 @@ __device__ __forceinline__ uint32_t ff_flags(uint32_t v) {
 // its own; the bytes after it start A = (8 - o % 8) % 8 bits into the chunk's stream, so lane t's four
 // shifted words come from one aligned 16-byte load at word 256 * step + 4 * t and the word behind it.
 // ------------------------------------------------------------------------------------------------
+// Sum of counts[0 .. c) (low 24 bits of each word) by one wave: the exclusive prefix a chunk needs, for launches
+// too small to be worth a scan kernel.
+__device__ __forceinline__ uint32_t wave_sum_before(const uint32_t* counts, uint32_t c, int lane) {
+    uint32_t s = 0;
+    for (uint32_t j = lane; j < c; j += 64) s += counts[j] & kCountMask;
+    return readlane_u32(wave_incl_scan_dpp(s), 63);
+}
+
 template <int SPEC>  // 1 KB steps requested before the chunk's length is known
 __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_count(StuffParams p, uint32_t n_chunks) {
     const int lane = threadIdx.x & 63;
@@ -911,7 +919,14 @@ __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_count(StuffParams p,
     }
     const uint32_t c = gid % p.cpi;
     const uint32_t n = p.chunk_bits[gid] & kCountMask;
-    const uint64_t o = p.bit_off[gid] + p.bit_base;
+    uint64_t o;
+    if (p.inline_scan) {  // uniform
+        o = wave_sum_before(p.chunk_bits + (gid - c), c, lane);
+        if (lane == 0) p.bit_off[gid] = o;
+        o += p.bit_base;
+    } else {
+        o = p.bit_off[gid] + p.bit_base;
+    }
     const uint32_t sbits = (uint32_t)(o & 7u);  // bits of the first owned byte that lie in the predecessor
     const uint32_t A = (8u - sbits) & 7u;
     const uint32_t nbytes = (uint32_t)(((o + n) >> 3) - (o >> 3));
@@ -996,7 +1011,8 @@ __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_write(StuffParams p,
     uint32_t* const out_words = p.words_out + (uint64_t)img * p.out_stride;
     uint8_t* const out_bytes = reinterpret_cast<uint8_t*>(out_words);
     const uint64_t cap_bytes = p.cap_words * 4;
-    const uint64_t pos0 = q_first + p.ff_off[gid] + p.ff_base;  // stuffed byte offset of the first owned byte
+    const uint64_t ff_before = p.inline_scan ? (uint64_t)wave_sum_before(p.chunk_ff + (gid - c), c, lane) : p.ff_off[gid];
+    const uint64_t pos0 = q_first + ff_before + p.ff_base;  // stuffed byte offset of the first owned byte
     uint64_t wbase = (pos0 >> 2) - p.out_word_base;             // index in out_words of stage[0]
     uint32_t head = (uint32_t)(pos0 & 3u);          // leading bytes of the stage's first word that belong to the previous chunk
     uint32_t fill = head;                           // bytes in the stage (uniform)
