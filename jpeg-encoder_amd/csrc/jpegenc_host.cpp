@@ -159,10 +159,13 @@ struct ProfScope {
     }
 };
 
-int pointer_align(const void* p, int64_t stride, int64_t image_stride, int n_images) {
+// 8: the kernel variant that addresses an image's pixels with 32-bit offsets from its first byte (buffer
+// loads), so every offset inside an image has to stay below 2^31 as well.
+int pointer_align(const void* p, int64_t stride, int64_t image_stride, int n_images, int rows) {
     uint64_t bits = reinterpret_cast<uintptr_t>(p) | uint64_t(stride);
     if (n_images > 1) bits |= uint64_t(image_stride);
-    if ((bits & 7) == 0) return 8;
+    const bool fits32 = stride > 0 && stride * int64_t(rows) < (int64_t(1) << 31);
+    if ((bits & 7) == 0 && fits32) return 8;
     if ((bits & 3) == 0) return 4;
     return 1;
 }
@@ -198,7 +201,7 @@ int encode_device(jpegenc_ctx* ctx, const uint8_t* rgb, int n_images, int w, int
     HIPCHK(ctx, ctx->bit_off.reserve(ws_chunks));
     HIPCHK(ctx, ctx->ff_off.reserve(ws_chunks));
 
-    const int align = pointer_align(rgb, stride, image_stride, n_images);
+    const int align = pointer_align(rgb, stride, image_stride, n_images, h);
 
     for (int first = 0; first < n_images; first += int(sub)) {
         const uint32_t n = uint32_t(std::min<int64_t>(sub, n_images - first));
@@ -521,7 +524,7 @@ int jpegenc_segment_encode(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int rows
     ep.htab = ctx->htab.p;
     ep.qmul = ctx->quant ? ctx->qmul.p : nullptr;
     // the block row above must be as aligned as the segment's own rows: the stride takes care of that
-    HIPCHK(ctx, launch_encode(ep, 1, pointer_align(d_rgb, d_stride, 0, 1), ctx->stream));
+    HIPCHK(ctx, launch_encode(ep, 1, pointer_align(d_rgb, d_stride, 0, 1, rows), ctx->stream));
     ScanParams sp;
     sp.counts = ctx->chunk_bits.p;
     sp.prefix = ctx->bit_off.p;

@@ -363,45 +363,8 @@ __device__ __forceinline__ void encode_block(const int (&blk)[64], int dc_pred, 
 // ------------------------------------------------------------------------------------------------
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-template <int ALIGN, bool LAST = false>
+template <int ALIGN>
 __device__ __forceinline__ void load_mcu(const uint8_t* src, int64_t stride, uint32_t (&raw)[48]) {
-    if constexpr (ALIGN == 8 && LAST) {
-        // The MCU's last fetch, streamed (nt): its lines may leave the L2 before those that other waves still
-        // need.  Written as one asm block because the compiler folds a non-temporal load into the identical
-        // plain one of the other components; the block waits for all its loads itself.
-        const uint8_t* r0 = src;
-        const uint8_t* r1 = src + stride;
-        const uint8_t* r2 = src + 2 * stride;
-        const uint8_t* r3 = src + 3 * stride;
-        const uint8_t* r4 = src + 4 * stride;
-        const uint8_t* r5 = src + 5 * stride;
-        const uint8_t* r6 = src + 6 * stride;
-        const uint8_t* r7 = src + 7 * stride;
-        u32x4 a0, a1, a2, a3, a4, a5, a6, a7;
-        u32x2 b0, b1, b2, b3, b4, b5, b6, b7;
-        asm volatile(
-            "global_load_dwordx4 %0, %16, off nt\n\tglobal_load_dwordx2 %8, %16, off offset:16 nt\n\t"
-            "global_load_dwordx4 %1, %17, off nt\n\tglobal_load_dwordx2 %9, %17, off offset:16 nt\n\t"
-            "global_load_dwordx4 %2, %18, off nt\n\tglobal_load_dwordx2 %10, %18, off offset:16 nt\n\t"
-            "global_load_dwordx4 %3, %19, off nt\n\tglobal_load_dwordx2 %11, %19, off offset:16 nt\n\t"
-            "global_load_dwordx4 %4, %20, off nt\n\tglobal_load_dwordx2 %12, %20, off offset:16 nt\n\t"
-            "global_load_dwordx4 %5, %21, off nt\n\tglobal_load_dwordx2 %13, %21, off offset:16 nt\n\t"
-            "global_load_dwordx4 %6, %22, off nt\n\tglobal_load_dwordx2 %14, %22, off offset:16 nt\n\t"
-            "global_load_dwordx4 %7, %23, off nt\n\tglobal_load_dwordx2 %15, %23, off offset:16 nt\n\t"
-            "s_waitcnt vmcnt(0)"
-            : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6), "=&v"(a7),
-              "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(b4), "=&v"(b5), "=&v"(b6), "=&v"(b7)
-            : "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(r4), "v"(r5), "v"(r6), "v"(r7)
-            : "memory");
-        const u32x4 a[8] = {a0, a1, a2, a3, a4, a5, a6, a7};
-        const u32x2 b[8] = {b0, b1, b2, b3, b4, b5, b6, b7};
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            raw[r * 6 + 0] = a[r].x; raw[r * 6 + 1] = a[r].y; raw[r * 6 + 2] = a[r].z;
-            raw[r * 6 + 3] = a[r].w; raw[r * 6 + 4] = b[r].x; raw[r * 6 + 5] = b[r].y;
-        }
-        return;
-    }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const uint8_t* row = src + (int64_t)r * stride;
@@ -420,6 +383,23 @@ __device__ __forceinline__ void load_mcu(const uint8_t* src, int64_t stride, uin
                 raw[r * 6 + i] = (uint32_t)row[4 * i] | ((uint32_t)row[4 * i + 1] << 8) |
                                  ((uint32_t)row[4 * i + 2] << 16) | ((uint32_t)row[4 * i + 3] << 24);
         }
+    }
+}
+
+// The same through buffer loads (8-byte-aligned rows, all offsets of an image below 2^31): one lane offset for
+// the whole MCU, the row's offset r * stride in a scalar register, so no 64-bit address per row.  LAST marks an
+// MCU's last fetch: non-temporal, its lines may leave the L2 ahead of lines that other waves still need.  (A
+// non-temporal global load would be folded into the identical plain load of the other components.)
+template <bool LAST>
+__device__ __forceinline__ void load_mcu_buf(__amdgpu_buffer_rsrc_t img, uint32_t lane_off, int32_t stride,
+                                             uint32_t (&raw)[48]) {
+    constexpr int aux = LAST ? 2 : 0;  // cache policy bit 1: nt
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(img, (int)lane_off, r * stride, aux);
+        const u32x2 b = __builtin_amdgcn_raw_buffer_load_b64(img, (int)lane_off + 16, r * stride, aux);
+        raw[r * 6 + 0] = a.x; raw[r * 6 + 1] = a.y; raw[r * 6 + 2] = a.z;
+        raw[r * 6 + 3] = a.w; raw[r * 6 + 4] = b.x; raw[r * 6 + 5] = b.y;
     }
 }
 
@@ -582,6 +562,11 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
     }
     const uint8_t* img_base = p.rgb + (int64_t)img * p.image_stride;
     const uint8_t* src = img_base + (int64_t)by * 8 * p.stride + (int64_t)bx * 24;
+    // ALIGN == 8 (the host grants it only when every offset inside an image is below 2^31): the image as a
+    // raw buffer and the MCU's first byte as a 32-bit offset into it
+    const __amdgpu_buffer_rsrc_t img_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img_base), 0, -1, 0x00020000);
+    const uint32_t lane_off = by * 8u * (uint32_t)p.stride + bx * 24u;
 
     // DC predictors for lane 0: the MCU just before this chunk (0 at the start of an image: rst)
     // (a segment that continues an image, flags bit 2, takes them from the last MCU of the block row above
@@ -640,10 +625,14 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
             // registers across the components spills at the register budget of three waves per SIMD,
             // and the scratch traffic then exceeds the saved fetches (measured).
             uint32_t raw[48];
-            if (comp == 2)
-                load_mcu<ALIGN, true>(src, p.stride, raw);  // the last fetch of these pixels
-            else
+            if constexpr (ALIGN == 8) {
+                if (comp == 2)
+                    load_mcu_buf<true>(img_rsrc, lane_off, (int32_t)p.stride, raw);  // the last fetch of these pixels
+                else
+                    load_mcu_buf<false>(img_rsrc, lane_off, (int32_t)p.stride, raw);
+            } else {
                 load_mcu<ALIGN>(src, p.stride, raw);
+            }
             // Two separately compiled bodies (shifts are immediates).  The differing asm comments keep
             // the optimiser from folding them back into one body with run-time shift counts.  Each row
             // is converted and transformed before the next one is touched, so the raw pixels die early.
