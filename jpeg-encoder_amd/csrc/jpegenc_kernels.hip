@@ -23,10 +23,6 @@
 #include "jpegenc_internal.h"
 #include "jpegenc_tables.h"
 
-#ifndef JPEGENC_SCHED_GROUP
-#define JPEGENC_SCHED_GROUP 4
-#endif
-
 namespace jpegenc {
 
 // ------------------------------------------------------------------------------------------------
