@@ -81,7 +81,9 @@ int jpegenc_default_config(jpegenc_config* cfg);
 int jpegenc_create(jpegenc_ctx** out, const jpegenc_config* cfg);
 int jpegenc_destroy(jpegenc_ctx* ctx);
 
-/* Makes the context launch on a caller-owned hipStream_t (pass NULL to go back to its own). */
+/* Makes the context launch on a caller-owned hipStream_t (pass NULL to go back to its own, which is a
+ * non-blocking stream: not ordered with the device's default stream.  To run on the default stream pass
+ * hipStreamLegacy, not NULL). */
 int jpegenc_set_stream(jpegenc_ctx* ctx, void* hip_stream);
 /* Blocks until everything enqueued by this context has finished. */
 int jpegenc_synchronize(jpegenc_ctx* ctx);

@@ -157,9 +157,16 @@ class JpegTop:
     def __exit__(self, *exc):
         self.close()
 
+    HIP_STREAM_LEGACY = 1  # hipStreamLegacy, the handle that names the device's default stream
+
     def set_stream(self, hip_stream):
-        """hip_stream: integer handle (e.g. torch.cuda.current_stream().cuda_stream) or None."""
-        self._check(self.lib.jpegenc_set_stream(self._ctx, C.c_void_p(hip_stream or None)))
+        """hip_stream: integer handle (e.g. torch.cuda.current_stream().cuda_stream), or None for the
+        context's own stream.  torch reports the device's default stream as handle 0, which the C ABI reads
+        as "own stream" (a non-blocking one, not ordered with the default stream): it is passed on as
+        hipStreamLegacy, so that work torch has queued on its default stream is ordered before the encoder's."""
+        if hip_stream is not None and int(hip_stream) == 0:
+            hip_stream = self.HIP_STREAM_LEGACY
+        self._check(self.lib.jpegenc_set_stream(self._ctx, C.c_void_p(hip_stream)))
 
     def synchronize(self):
         self._check(self.lib.jpegenc_synchronize(self._ctx))

@@ -350,6 +350,35 @@ def test_device_pointers_strides_and_alignment():
                 assert_same(words[i, :k], res[i], imgs[i])
 
 
+def test_row_strides_around_the_32_bit_offset_limit():
+    """The 8-byte-aligned kernel variant addresses an image with 32-bit offsets from its first byte and is
+    used while rows * stride < 2^31: a 2 GiB device buffer holds a 16-row image at a stride just below that
+    bound (largest offsets the variant sees) and at the bound (the 64-bit-address variant takes over)."""
+    torch = pytest.importorskip("torch")
+    pkg = load_pkg()
+    dev = torch.device("cuda:0")
+    h, w = 16, 192
+    img = np.random.default_rng(77).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    d_img = torch.from_numpy(img.reshape(h, w * 3)).to(dev)
+    cap = pkg.max_words(w, h)
+    d_buf = torch.zeros((1 << 31) + 4096, dtype=torch.uint8, device=dev)
+    with pkg.JpegTop(stream=torch.cuda.current_stream().cuda_stream) as e:
+        for stride in ((1 << 27) - 8, 1 << 27):
+            d_buf.zero_()
+            for r in range(h):
+                d_buf[r * stride:r * stride + w * 3] = d_img[r]
+            d_words = torch.zeros((1, cap), dtype=torch.int32, device=dev)
+            d_res = torch.zeros((1, 32), dtype=torch.uint8, device=dev)
+            e.encode_batch_device(d_buf.data_ptr(), 1, w, h, stride, stride * h, d_words.data_ptr(), cap,
+                                  d_res.data_ptr())
+            torch.cuda.synchronize()
+            res = d_res.cpu().numpy().view(pkg.RESULT_DTYPE).reshape(1)
+            words = d_words.cpu().numpy().view(np.uint32)
+            k = int(res[0]["n_full_words"]) + (1 if res[0]["tail_bits"] else 0)
+            assert_same(words[0, :k], res[0], img)
+    del d_buf
+
+
 def test_4k_batch_properties():
     """Config-2 shape (3840x2160 frames, device resident) at a bounded count: two frames are checked
     word for word against the oracle, the rest through size-independent properties -- equal images give
