@@ -39,7 +39,9 @@ extern "C" {
                                   multiples of 8; the last column and row are repeated up to the next multiples
                                   and the padded image is coded (jpegenc_encode_rgb8 / _batch only) */
 #define JPEGENC_DEVICE_PTRS 1u /* all three are device memory on the context's device; the call
-                                  only enqueues work on the context's stream */
+                                  only enqueues work on the context's stream -- except when the
+                                  context's workspace has to grow for it: then it allocates, which
+                                  synchronises the device (see jpegenc_reserve) */
 
 typedef struct jpegenc_ctx jpegenc_ctx;
 
@@ -83,7 +85,10 @@ int jpegenc_destroy(jpegenc_ctx* ctx);
 
 /* Makes the context launch on a caller-owned hipStream_t (pass NULL to go back to its own, which is a
  * non-blocking stream: not ordered with the device's default stream.  To run on the default stream pass
- * hipStreamLegacy, not NULL). */
+ * hipStreamLegacy, not NULL).  All calls of a context share its workspace, so work it has queued on the
+ * stream it leaves is ordered before anything later queued on the new one (the new stream is made to
+ * wait for an event); calls of one context therefore never overlap, whatever streams they run on --
+ * use one context per stream for concurrency. */
 int jpegenc_set_stream(jpegenc_ctx* ctx, void* hip_stream);
 /* Blocks until everything enqueued by this context has finished. */
 int jpegenc_synchronize(jpegenc_ctx* ctx);
@@ -136,7 +141,10 @@ int jpegenc_encode_stripes(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int h, p
  *      band also fills `result` (host memory) with the whole stream's figures (its tail_word holds
  *      this band's bytes only: if the band before it shares that word, take it from the ORed words).
  * `flags`: JPEGENC_HOST_PTRS/JPEGENC_DEVICE_PTRS for rgb resp. words_out, ORed with
- * JPEGENC_SEG_CONTINUES in step 1 for every band but the first.  The calls synchronise the stream. */
+ * JPEGENC_SEG_CONTINUES in step 1 for every band but the first.  Every one of the three calls ends with
+ * a stream synchronisation and small device-to-host copies (the counts it returns), and step 1 may
+ * allocate.  The band's chunk streams stay in the context's workspace between the steps: any other
+ * encode call on the context in between discards them, and steps 2 and 3 then return JPEGENC_E_STATE. */
 #define JPEGENC_SEG_CONTINUES 2u
 int jpegenc_segment_encode(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int rows, ptrdiff_t stride, uint32_t flags,
                            uint64_t* bits, uint32_t* tail8);
@@ -172,8 +180,17 @@ int jpegenc_kernel_times(jpegenc_ctx* ctx, uint64_t launches[JPEGENC_N_KERNELS],
 const char* jpegenc_kernel_name(int index);
 
 /* Scratch memory budget in bytes for the intermediate chunk streams (default 32 GiB); a batch is
- * processed in sub-batches that fit. */
+ * processed in sub-batches that fit (39 936 bytes per 64 blocks: 20.2 MB per 1080p frame, touched only
+ * as far as the frame's stream is long).  Host-pointer batches are also staged in groups of images
+ * whose input and output copies fit the budget.  When the device cannot provide the budget the
+ * sub-batches are halved until they fit; JPEGENC_E_NOMEM when not even one image does. */
 int jpegenc_set_workspace_limit(jpegenc_ctx* ctx, size_t bytes);
+
+/* Grows the workspace now to what jpegenc_encode_batch(n_images, w, h) will need (under the limit
+ * above), so that later device-pointer calls of at most that size only enqueue work: no allocation, no
+ * device synchronisation.  The workspace never shrinks before jpegenc_destroy.  No counterpart in
+ * jpeg_top (hardware has no allocator). */
+int jpegenc_reserve(jpegenc_ctx* ctx, int n_images, int w, int h);
 
 const char* jpegenc_strerror(int code);
 /* Text of the last HIP error seen by this context ("" if none). */

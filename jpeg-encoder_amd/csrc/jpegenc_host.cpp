@@ -1,5 +1,6 @@
 // jpegenc_host.cpp -- C ABI of libjpegenc.so (include/jpegenc.h): context, workspace, launch sequencing.
 // The compute path is the HIP kernels in jpegenc_kernels.hip; there is no CPU fallback in this library.
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -99,6 +100,11 @@ struct jpegenc_ctx {
     DevBuf<uint32_t> out_stage;
     DevBuf<jpegenc_result> res_stage;
 
+    // Recorded on the stream after every group of launches that uses the workspace: a later call on another
+    // stream (jpegenc_set_stream) waits for it before it touches the workspace again.
+    hipEvent_t ws_event = nullptr;
+    bool ws_pending = false;
+
     // segment API: what jpegenc_segment_encode left in the workspace
     bool seg_ready = false, seg_counted = false;
     uint32_t seg_cpi = 0;
@@ -129,10 +135,37 @@ int fail_hip(jpegenc_ctx* ctx, hipError_t e, const char* what) {
     return JPEGENC_E_HIP;
 }
 
+// Makes the context's device current for the duration of a call and puts the caller's back afterwards.
+struct DevGuard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DevGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) err = hipSetDevice(dev);
+    }
+    ~DevGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DevGuard(const DevGuard&) = delete;
+    DevGuard& operator=(const DevGuard&) = delete;
+};
+
 #define HIPCHK(ctx, expr)                                       \
     do {                                                        \
         hipError_t e_ = (expr);                                 \
         if (e_ != hipSuccess) return fail_hip(ctx, e_, #expr);  \
+    } while (0)
+
+// For allocations: running out of device memory is JPEGENC_E_NOMEM, not a HIP failure.
+#define MEMCHK(ctx, expr)                                                  \
+    do {                                                                   \
+        hipError_t e_ = (expr);                                            \
+        if (e_ == hipErrorOutOfMemory) {                                   \
+            (void)hipGetLastError();                                       \
+            (ctx)->last_error = "device memory exhausted: " #expr;         \
+            return JPEGENC_E_NOMEM;                                        \
+        }                                                                  \
+        if (e_ != hipSuccess) return fail_hip(ctx, e_, #expr);             \
     } while (0)
 
 // Event pairs wait in the context until jpegenc_kernel_times collects them; beyond this many the launches
@@ -146,7 +179,12 @@ struct ProfScope {
     ProfScope(jpegenc_ctx* c, int kernel) : ctx(c), on(c->profiling && c->events.size() < kMaxPendingEvents) {
         if (!on) return;
         ep.kernel = kernel;
-        if (hipEventCreate(&ep.a) != hipSuccess || hipEventCreate(&ep.b) != hipSuccess) {
+        if (hipEventCreate(&ep.a) != hipSuccess) {
+            on = false;
+            return;
+        }
+        if (hipEventCreate(&ep.b) != hipSuccess) {
+            (void)hipEventDestroy(ep.a);
             on = false;
             return;
         }
@@ -177,92 +215,160 @@ int pointer_align(const void* p, int64_t stride, int64_t image_stride, int n_ima
 constexpr uint64_t kInlineScanChunks = 8192;
 constexpr uint32_t kInlineScanMaxCpi = 8192;
 
-// All pointers are device memory.  Enqueues the whole pipeline on ctx->stream.
-int encode_device(jpegenc_ctx* ctx, const uint8_t* rgb, int n_images, int w, int h, ptrdiff_t stride,
-                  ptrdiff_t image_stride, uint32_t* words, size_t cap_words, jpegenc_result* results) {
-    const uint32_t mcu_w = uint32_t(w / 8), mcu_h = uint32_t(h / 8);
-    const uint64_t n_mcu64 = uint64_t(mcu_w) * mcu_h;
-    if (n_mcu64 > 0x7FFFFFFFull) return JPEGENC_E_UNSUPPORTED;
-    const uint32_t n_mcu = uint32_t(n_mcu64);
-    const uint32_t cpi = (n_mcu + kChunkMcus - 1) / kChunkMcus;
-    const size_t slot_bytes = size_t(kSlotWords) * 4;
+// Geometry of a call and the number of images one launch group holds under the workspace budget.
+struct Plan {
+    uint32_t mcu_w, n_mcu, cpi;
+    uint32_t sub;  // images per launch group
+};
 
-    // sub-batch size: as many images as fit the workspace budget (at least one)
-    uint64_t per_image = uint64_t(cpi) * slot_bytes;
-    uint32_t sub = uint32_t(ctx->ws_limit / (per_image ? per_image : 1));
+int make_plan(const jpegenc_ctx* ctx, int n_images, int w, int h, Plan* pl) {
+    pl->mcu_w = uint32_t(w / 8);
+    const uint64_t n_mcu64 = uint64_t(pl->mcu_w) * uint32_t(h / 8);
+    if (n_mcu64 == 0 || n_mcu64 > 0x7FFFFFFFull) return JPEGENC_E_UNSUPPORTED;
+    pl->n_mcu = uint32_t(n_mcu64);
+    pl->cpi = (pl->n_mcu + kChunkMcus - 1) / kChunkMcus;
+    const uint64_t per_image = uint64_t(pl->cpi) * kSlotWords * 4;
+    uint64_t sub = ctx->ws_limit / per_image;
     if (sub < 1) sub = 1;
-    if (sub > uint32_t(n_images)) sub = uint32_t(n_images);
-    while (uint64_t(sub) * cpi > 0x7FFFFFF0ull) sub /= 2;  // grid limit
-    const size_t ws_chunks = size_t(sub) * cpi;
+    if (sub > uint64_t(n_images)) sub = uint64_t(n_images);
+    while (sub * pl->cpi > 0x7FFFFFF0ull) sub /= 2;  // grid limit
+    pl->sub = uint32_t(sub);
+    return JPEGENC_OK;
+}
 
-    HIPCHK(ctx, ctx->slots.reserve((ws_chunks + 1) * size_t(kSlotWords)));
-    HIPCHK(ctx, ctx->chunk_bits.reserve(ws_chunks));
-    HIPCHK(ctx, ctx->chunk_ff.reserve(ws_chunks));
-    HIPCHK(ctx, ctx->bit_off.reserve(ws_chunks));
-    HIPCHK(ctx, ctx->ff_off.reserve(ws_chunks));
+hipError_t reserve_workspace(jpegenc_ctx* ctx, size_t chunks) {
+    hipError_t e = ctx->slots.reserve((chunks + 1) * size_t(kSlotWords));
+    if (e == hipSuccess) e = ctx->chunk_bits.reserve(chunks);
+    if (e == hipSuccess) e = ctx->chunk_ff.reserve(chunks);
+    if (e == hipSuccess) e = ctx->bit_off.reserve(chunks);
+    if (e == hipSuccess) e = ctx->ff_off.reserve(chunks);
+    return e;
+}
 
-    const int align = pointer_align(rgb, stride, image_stride, n_images, h);
+// Grows the workspace for the plan.  When the device has no room for it (another allocator may hold most of
+// the memory) the launch groups are halved until they fit, down to one image.
+int reserve_for_plan(jpegenc_ctx* ctx, Plan* pl) {
+    for (;;) {
+        const hipError_t e = reserve_workspace(ctx, size_t(pl->sub) * pl->cpi);
+        if (e == hipSuccess) return JPEGENC_OK;
+        if (e != hipErrorOutOfMemory) return fail_hip(ctx, e, "workspace allocation");
+        (void)hipGetLastError();  // the failed allocation is not left behind as a pending error
+        if (pl->sub == 1) {
+            ctx->last_error = "device memory exhausted: the workspace for one image does not fit";
+            return JPEGENC_E_NOMEM;
+        }
+        pl->sub = (pl->sub + 1) / 2;
+    }
+}
 
-    for (int first = 0; first < n_images; first += int(sub)) {
-        const uint32_t n = uint32_t(std::min<int64_t>(sub, n_images - first));
-        EncodeParams ep;
-        ep.rgb = rgb + int64_t(first) * image_stride;
-        ep.stride = stride;
-        ep.image_stride = image_stride;
-        ep.mcu_w = mcu_w;
-        ep.n_mcu = n_mcu;
-        ep.cpi = cpi;
-        ep.flags = ctx->flags;
-        ep.slots = ctx->slots.p;
-        ep.chunk_bits = ctx->chunk_bits.p;
-        ep.htab = ctx->htab.p;
-        ep.qmul = ctx->quant ? ctx->qmul.p : nullptr;
-        {
-            ProfScope ps(ctx, K_ENCODE);
-            HIPCHK(ctx, launch_encode(ep, n, align, ctx->stream));
-        }
-        // a frame or a few: the stuffing kernels work out the prefixes themselves, two launches fewer
-        const bool inline_scan = uint64_t(n) * cpi <= kInlineScanChunks && cpi <= kInlineScanMaxCpi;
-        ScanParams sp;
-        sp.counts = ctx->chunk_bits.p;
-        sp.prefix = ctx->bit_off.p;
-        sp.cpi = cpi;
-        if (!inline_scan) {
-            ProfScope ps(ctx, K_SCAN);
-            HIPCHK(ctx, launch_scan(sp, n, ctx->stream));
-        }
-        StuffParams tp;
-        tp.slots = ctx->slots.p;
-        tp.chunk_bits = ctx->chunk_bits.p;
-        tp.bit_off = ctx->bit_off.p;
-        tp.chunk_ff = ctx->chunk_ff.p;
-        tp.ff_off = ctx->ff_off.p;
-        tp.words_out = words + uint64_t(first) * cap_words;
-        tp.out_stride = cap_words;
-        tp.cap_words = cap_words;
-        tp.results = results + first;
-        tp.cpi = cpi;
-        tp.pred_tail8 = 0;
-        tp.bit_base = tp.ff_base = tp.out_word_base = 0;
-        tp.eof = 1;
-        tp.spec_depth = ctx->quant ? 1u : 5u;
-        tp.inline_scan = inline_scan ? 1u : 0u;
-        {
-            ProfScope ps(ctx, K_STUFF_COUNT);
-            HIPCHK(ctx, launch_stuff_count(tp, n, ctx->stream));
-        }
-        sp.counts = ctx->chunk_ff.p;
-        sp.prefix = ctx->ff_off.p;
-        if (!inline_scan) {
-            ProfScope ps(ctx, K_SCAN);
-            HIPCHK(ctx, launch_scan(sp, n, ctx->stream));
-        }
-        {
-            ProfScope ps(ctx, K_STUFF_WRITE);
-            HIPCHK(ctx, launch_stuff_write(tp, n, ctx->stream));
-        }
+Workspace ctx_workspace(const jpegenc_ctx* ctx) {
+    Workspace ws;
+    ws.slots = ctx->slots.p;
+    ws.chunk_bits = ctx->chunk_bits.p;
+    ws.chunk_ff = ctx->chunk_ff.p;
+    ws.bit_off = ctx->bit_off.p;
+    ws.ff_off = ctx->ff_off.p;
+    return ws;
+}
+
+// Marks the workspace as in use by what has just been enqueued on the context's stream.
+int workspace_used(jpegenc_ctx* ctx) {
+    HIPCHK(ctx, hipEventRecord(ctx->ws_event, ctx->stream));
+    ctx->ws_pending = true;
+    return JPEGENC_OK;
+}
+
+// The launches for n images (one launch group) with the workspace `ws`.  All pointers are device memory.
+// `timed`: bracket the kernels with events when profiling is on (creates events).
+int run_group(jpegenc_ctx* ctx, const Workspace& ws, bool timed, const Plan& pl, const uint8_t* rgb, uint32_t n,
+              ptrdiff_t stride, ptrdiff_t image_stride, int align, uint32_t* words, size_t cap_words,
+              jpegenc_result* results) {
+    const bool prof_was = ctx->profiling;
+    if (!timed) ctx->profiling = false;
+    struct Restore {
+        jpegenc_ctx* c;
+        bool v;
+        ~Restore() { c->profiling = v; }
+    } restore{ctx, prof_was};
+    const uint32_t cpi = pl.cpi;
+    EncodeParams ep;
+    ep.rgb = rgb;
+    ep.stride = stride;
+    ep.image_stride = image_stride;
+    ep.mcu_w = pl.mcu_w;
+    ep.n_mcu = pl.n_mcu;
+    ep.cpi = cpi;
+    ep.flags = ctx->flags;
+    ep.slots = ws.slots;
+    ep.chunk_bits = ws.chunk_bits;
+    ep.htab = ctx->htab.p;
+    ep.qmul = ctx->quant ? ctx->qmul.p : nullptr;
+    {
+        ProfScope ps(ctx, K_ENCODE);
+        HIPCHK(ctx, launch_encode(ep, n, align, ctx->stream));
+    }
+    // a frame or a few: the stuffing kernels work out the prefixes themselves, two launches fewer
+    const bool inline_scan = uint64_t(n) * cpi <= kInlineScanChunks && cpi <= kInlineScanMaxCpi;
+    ScanParams sp;
+    sp.counts = ws.chunk_bits;
+    sp.prefix = ws.bit_off;
+    sp.cpi = cpi;
+    if (!inline_scan) {
+        ProfScope ps(ctx, K_SCAN);
+        HIPCHK(ctx, launch_scan(sp, n, ctx->stream));
+    }
+    StuffParams tp;
+    tp.slots = ws.slots;
+    tp.chunk_bits = ws.chunk_bits;
+    tp.bit_off = ws.bit_off;
+    tp.chunk_ff = ws.chunk_ff;
+    tp.ff_off = ws.ff_off;
+    tp.words_out = words;
+    tp.out_stride = cap_words;
+    tp.cap_words = cap_words;
+    tp.results = results;
+    tp.cpi = cpi;
+    tp.pred_tail8 = 0;
+    tp.bit_base = tp.ff_base = tp.out_word_base = 0;
+    tp.eof = 1;
+    tp.spec_depth = ctx->quant ? 1u : 5u;
+    tp.inline_scan = inline_scan ? 1u : 0u;
+    {
+        ProfScope ps(ctx, K_STUFF_COUNT);
+        HIPCHK(ctx, launch_stuff_count(tp, n, ctx->stream));
+    }
+    sp.counts = ws.chunk_ff;
+    sp.prefix = ws.ff_off;
+    if (!inline_scan) {
+        ProfScope ps(ctx, K_SCAN);
+        HIPCHK(ctx, launch_scan(sp, n, ctx->stream));
+    }
+    {
+        ProfScope ps(ctx, K_STUFF_WRITE);
+        HIPCHK(ctx, launch_stuff_write(tp, n, ctx->stream));
     }
     return JPEGENC_OK;
+}
+
+// All pointers are device memory.  Enqueues the whole pipeline on ctx->stream; allocates (and thereby
+// synchronises the device) only when the workspace has to grow.
+int encode_device(jpegenc_ctx* ctx, const uint8_t* rgb, int n_images, int w, int h, ptrdiff_t stride,
+                  ptrdiff_t image_stride, uint32_t* words, size_t cap_words, jpegenc_result* results) {
+    Plan pl;
+    int rc = make_plan(ctx, n_images, w, h, &pl);
+    if (rc != JPEGENC_OK) return rc;
+    ctx->seg_ready = ctx->seg_counted = false;  // whatever a segment call left in the workspace is gone
+    rc = reserve_for_plan(ctx, &pl);
+    if (rc != JPEGENC_OK) return rc;
+    const Workspace ws = ctx_workspace(ctx);
+    const int align = pointer_align(rgb, stride, image_stride, n_images, h);
+    for (int first = 0; first < n_images; first += int(pl.sub)) {
+        const uint32_t n = uint32_t(std::min<int64_t>(pl.sub, n_images - first));
+        rc = run_group(ctx, ws, true, pl, rgb + int64_t(first) * image_stride, n, stride, image_stride, align,
+                       words + uint64_t(first) * cap_words, cap_words, results + first);
+        if (rc != JPEGENC_OK) return rc;
+    }
+    return workspace_used(ctx);
 }
 
 int check_dims(const void* rgb, int n, int w, int h, ptrdiff_t stride, const void* words, const void* results,
@@ -280,9 +386,9 @@ int encode_host(jpegenc_ctx* ctx, const uint8_t* rgb, int n_images, int w, int h
                 ptrdiff_t image_stride, uint32_t* words, size_t cap_words, jpegenc_result* results) {
     const size_t row = size_t(w) * 3;
     const size_t img_bytes = row * size_t(h);
-    HIPCHK(ctx, ctx->in_stage.reserve(img_bytes * size_t(n_images)));
-    HIPCHK(ctx, ctx->out_stage.reserve(cap_words * size_t(n_images)));
-    HIPCHK(ctx, ctx->res_stage.reserve(size_t(n_images)));
+    MEMCHK(ctx, ctx->in_stage.reserve(img_bytes * size_t(n_images)));
+    MEMCHK(ctx, ctx->out_stage.reserve(cap_words * size_t(n_images)));
+    MEMCHK(ctx, ctx->res_stage.reserve(size_t(n_images)));
     for (int i = 0; i < n_images; ++i)
         HIPCHK(ctx, hipMemcpy2DAsync(ctx->in_stage.p + img_bytes * size_t(i), row, rgb + int64_t(i) * image_stride,
                                      size_t(stride), row, size_t(h), hipMemcpyHostToDevice, ctx->stream));
@@ -294,8 +400,8 @@ int encode_staged(jpegenc_ctx* ctx, const uint8_t* d_rgb, int n_images, int w, i
                   jpegenc_result* results) {
     const size_t row = size_t(w) * 3;
     const size_t img_bytes = row * size_t(h);
-    HIPCHK(ctx, ctx->out_stage.reserve(cap_words * size_t(n_images)));
-    HIPCHK(ctx, ctx->res_stage.reserve(size_t(n_images)));
+    MEMCHK(ctx, ctx->out_stage.reserve(cap_words * size_t(n_images)));
+    MEMCHK(ctx, ctx->res_stage.reserve(size_t(n_images)));
     int rc = encode_device(ctx, d_rgb, n_images, w, h, ptrdiff_t(row), ptrdiff_t(img_bytes), ctx->out_stage.p, cap_words,
                            ctx->res_stage.p);
     if (rc != JPEGENC_OK) return rc;
@@ -344,7 +450,8 @@ int jpegenc_create(jpegenc_ctx** out, const jpegenc_config* cfg) {
     if (!ctx) return JPEGENC_E_NOMEM;
     ctx->cfg = *cfg;
     ctx->device = cfg->device;
-    hipError_t e = hipSetDevice(ctx->device);
+    DevGuard guard(ctx->device);
+    hipError_t e = guard.err;
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, ctx->device);
     if (e == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
@@ -352,7 +459,9 @@ int jpegenc_create(jpegenc_ctx** out, const jpegenc_config* cfg) {
         return JPEGENC_E_HIP;  // the code object is gfx950-only
     }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ws_event, hipEventDisableTiming);
     if (e != hipSuccess) {
+        if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
         delete ctx;
         return JPEGENC_E_HIP;
     }
@@ -387,8 +496,9 @@ int jpegenc_create(jpegenc_ctx** out, const jpegenc_config* cfg) {
 
 int jpegenc_destroy(jpegenc_ctx* ctx) {
     if (!ctx) return JPEGENC_E_BAD_ARG;
-    (void)hipSetDevice(ctx->device);
+    DevGuard guard(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ws_event) (void)hipEventDestroy(ctx->ws_event);
     for (auto& ep : ctx->events) {
         (void)hipEventDestroy(ep.a);
         (void)hipEventDestroy(ep.b);
@@ -411,13 +521,22 @@ int jpegenc_destroy(jpegenc_ctx* ctx) {
 
 int jpegenc_set_stream(jpegenc_ctx* ctx, void* hip_stream) {
     if (!ctx) return JPEGENC_E_BAD_ARG;
-    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    const hipStream_t next = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    if (next != ctx->stream && ctx->ws_pending) {
+        // every call shares the context's workspace: what is still queued on the old stream has to finish
+        // with it before anything on the new stream may overwrite it
+        DevGuard guard(ctx->device);
+        HIPCHK(ctx, guard.err);
+        HIPCHK(ctx, hipStreamWaitEvent(next, ctx->ws_event, 0));
+    }
+    ctx->stream = next;
     return JPEGENC_OK;
 }
 
 int jpegenc_synchronize(jpegenc_ctx* ctx) {
     if (!ctx) return JPEGENC_E_BAD_ARG;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevGuard guard(ctx->device);
+    HIPCHK(ctx, guard.err);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return JPEGENC_OK;
 }
@@ -438,7 +557,28 @@ int jpegenc_encode_batch(jpegenc_ctx* ctx, const uint8_t* rgb, int n_images, int
     if (cap_words_per_image == 0) return JPEGENC_E_BAD_ARG;
     if (n_images > 1 && (image_stride < 0 ? -image_stride : image_stride) < stride * ptrdiff_t(h) && image_stride != 0)
         return JPEGENC_E_BAD_ARG;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevGuard guard(ctx->device);
+    HIPCHK(ctx, guard.err);
+    if (!(flags & JPEGENC_DEVICE_PTRS) && n_images > 1) {
+        // host memory: the staging copies of input and output count against the workspace budget too, so a
+        // large batch goes through in groups of images
+        const uint64_t per_image = uint64_t(w) * 3 * uint64_t(h) * (pad ? 2 : 1) + uint64_t(cap_words_per_image) * 4;
+        const uint64_t group = std::max<uint64_t>(1, ctx->ws_limit / per_image);
+        if (group < uint64_t(n_images)) {
+            int worst = JPEGENC_OK;
+            for (int first = 0; first < n_images; first += int(group)) {
+                const int n = int(std::min<uint64_t>(group, uint64_t(n_images - first)));
+                rc = jpegenc_encode_batch(ctx, rgb + int64_t(first) * image_stride, n, w, h, stride, image_stride, flags,
+                                          words_out + size_t(first) * cap_words_per_image, cap_words_per_image,
+                                          results + first);
+                if (rc == JPEGENC_E_TOO_SMALL)
+                    worst = rc;  // reported per image; the other groups are still coded
+                else if (rc != JPEGENC_OK)
+                    return rc;
+            }
+            return worst;
+        }
+    }
     if (pad) {
         // extension (not in jpeg_top): replicate the right and bottom edges up to multiples of 8 on the
         // device, then code the padded images
@@ -447,7 +587,7 @@ int jpegenc_encode_batch(jpegenc_ctx* ctx, const uint8_t* rgb, int n_images, int
         const uint8_t* d_src = rgb;
         ptrdiff_t s_stride = stride, s_istride = image_stride;
         if (!(flags & JPEGENC_DEVICE_PTRS)) {
-            HIPCHK(ctx, ctx->in_stage.reserve(row * size_t(h) * size_t(n_images)));
+            MEMCHK(ctx, ctx->in_stage.reserve(row * size_t(h) * size_t(n_images)));
             for (int i = 0; i < n_images; ++i)
                 HIPCHK(ctx, hipMemcpy2DAsync(ctx->in_stage.p + row * size_t(h) * size_t(i), row,
                                              rgb + int64_t(i) * image_stride, size_t(stride), row, size_t(h),
@@ -456,7 +596,7 @@ int jpegenc_encode_batch(jpegenc_ctx* ctx, const uint8_t* rgb, int n_images, int
             s_stride = ptrdiff_t(row);
             s_istride = ptrdiff_t(row * size_t(h));
         }
-        HIPCHK(ctx, ctx->pad_stage.reserve(padded * size_t(n_images)));
+        MEMCHK(ctx, ctx->pad_stage.reserve(padded * size_t(n_images)));
         HIPCHK(ctx, launch_pad_edges(d_src, s_stride, s_istride, w, h, n_images, ctx->pad_stage.p, ctx->stream));
         if (flags & JPEGENC_DEVICE_PTRS)
             return encode_device(ctx, ctx->pad_stage.p, n_images, w8, h8, ptrdiff_t(w8) * 3, ptrdiff_t(padded), words_out,
@@ -466,6 +606,17 @@ int jpegenc_encode_batch(jpegenc_ctx* ctx, const uint8_t* rgb, int n_images, int
     if (flags & JPEGENC_DEVICE_PTRS)
         return encode_device(ctx, rgb, n_images, w, h, stride, image_stride, words_out, cap_words_per_image, results);
     return encode_host(ctx, rgb, n_images, w, h, stride, image_stride, words_out, cap_words_per_image, results);
+}
+
+int jpegenc_reserve(jpegenc_ctx* ctx, int n_images, int w, int h) {
+    if (!ctx || n_images <= 0 || w <= 0 || h <= 0) return JPEGENC_E_BAD_ARG;
+    DevGuard guard(ctx->device);
+    HIPCHK(ctx, guard.err);
+    Plan pl;
+    const int rc = make_plan(ctx, n_images, (w + 7) & ~7, (h + 7) & ~7, &pl);
+    if (rc != JPEGENC_OK) return rc;
+    ctx->seg_ready = ctx->seg_counted = false;  // growing the workspace discards a segment's chunk streams
+    return reserve_for_plan(ctx, &pl);
 }
 
 int jpegenc_encode_rgb8(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int h, ptrdiff_t stride, uint32_t flags,
@@ -488,7 +639,8 @@ int jpegenc_segment_encode(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int rows
                            uint64_t* bits, uint32_t* tail8) {
     if (!ctx || !rgb || !bits || !tail8) return JPEGENC_E_BAD_ARG;
     if (w <= 0 || rows <= 0 || (w % 8) || (rows % 8) || stride < ptrdiff_t(w) * 3) return JPEGENC_E_BAD_ARG;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevGuard guard(ctx->device);
+    HIPCHK(ctx, guard.err);
     ctx->seg_ready = ctx->seg_counted = false;
     const bool continues = (flags & JPEGENC_SEG_CONTINUES) != 0;
     const uint8_t* d_rgb = rgb;
@@ -496,7 +648,7 @@ int jpegenc_segment_encode(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int rows
     if (!(flags & JPEGENC_DEVICE_PTRS)) {
         const size_t row = size_t(w) * 3;
         const int halo = continues ? 8 : 0;
-        HIPCHK(ctx, ctx->in_stage.reserve(row * size_t(rows + halo)));
+        MEMCHK(ctx, ctx->in_stage.reserve(row * size_t(rows + halo)));
         HIPCHK(ctx, hipMemcpy2DAsync(ctx->in_stage.p, row, rgb - ptrdiff_t(halo) * stride, size_t(stride), row,
                                      size_t(rows + halo), hipMemcpyHostToDevice, ctx->stream));
         d_rgb = ctx->in_stage.p + row * size_t(halo);
@@ -506,11 +658,15 @@ int jpegenc_segment_encode(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int rows
     const uint64_t n_mcu64 = uint64_t(mcu_w) * uint32_t(rows / 8);
     if (n_mcu64 > 0x7FFFFFFFull) return JPEGENC_E_UNSUPPORTED;
     const uint32_t cpi = uint32_t((n_mcu64 + kChunkMcus - 1) / kChunkMcus);
-    HIPCHK(ctx, ctx->slots.reserve((size_t(cpi) + 1) * size_t(kSlotWords)));
-    HIPCHK(ctx, ctx->chunk_bits.reserve(cpi));
-    HIPCHK(ctx, ctx->chunk_ff.reserve(cpi));
-    HIPCHK(ctx, ctx->bit_off.reserve(cpi));
-    HIPCHK(ctx, ctx->ff_off.reserve(cpi));
+    {
+        const hipError_t e = reserve_workspace(ctx, cpi);
+        if (e == hipErrorOutOfMemory) {
+            (void)hipGetLastError();
+            ctx->last_error = "device memory exhausted: the workspace for this segment does not fit";
+            return JPEGENC_E_NOMEM;
+        }
+        HIPCHK(ctx, e);
+    }
     EncodeParams ep;
     ep.rgb = d_rgb;
     ep.stride = d_stride;
@@ -570,7 +726,8 @@ StuffParams segment_params(jpegenc_ctx* ctx) {
 int jpegenc_segment_count(jpegenc_ctx* ctx, uint64_t bit_offset, uint32_t prev_tail8, uint64_t* ff_bytes) {
     if (!ctx || !ff_bytes) return JPEGENC_E_BAD_ARG;
     if (!ctx->seg_ready) return JPEGENC_E_STATE;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevGuard guard(ctx->device);
+    HIPCHK(ctx, guard.err);
     ctx->seg_bit_offset = bit_offset;
     ctx->seg_prev_tail8 = prev_tail8 & 0xFFu;
     StuffParams tp = segment_params(ctx);
@@ -596,7 +753,8 @@ int jpegenc_segment_write(jpegenc_ctx* ctx, uint64_t ff_offset, int is_last, uin
     if (!ctx || !words_out || !first_word || !n_words || cap_words == 0) return JPEGENC_E_BAD_ARG;
     if (is_last && !result) return JPEGENC_E_BAD_ARG;
     if (!ctx->seg_ready || !ctx->seg_counted) return JPEGENC_E_STATE;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevGuard guard(ctx->device);
+    HIPCHK(ctx, guard.err);
     const uint64_t o = ctx->seg_bit_offset, end_bits = o + ctx->seg_bits;
     const uint64_t pos0 = (o >> 3) + ff_offset;
     const uint64_t end_pos = (end_bits >> 3) + ff_offset + ctx->seg_ff;  // stuffed bytes of the whole stream so far
@@ -607,10 +765,10 @@ int jpegenc_segment_write(jpegenc_ctx* ctx, uint64_t ff_offset, int is_last, uin
     const size_t n_store = size_t(std::min<uint64_t>(*n_words, cap_words));
     uint32_t* d_words = words_out;
     if (!(flags & JPEGENC_DEVICE_PTRS)) {
-        HIPCHK(ctx, ctx->out_stage.reserve(cap_words));
+        MEMCHK(ctx, ctx->out_stage.reserve(cap_words));
         d_words = ctx->out_stage.p;
     }
-    HIPCHK(ctx, ctx->res_stage.reserve(1));
+    MEMCHK(ctx, ctx->res_stage.reserve(1));
     // bytes of boundary words that belong to the neighbouring segments stay zero: the caller ORs those words
     HIPCHK(ctx, hipMemsetAsync(d_words, 0, n_store * 4, ctx->stream));
     StuffParams tp = segment_params(ctx);
@@ -709,7 +867,8 @@ int jpegenc_set_profiling(jpegenc_ctx* ctx, int enable) {
 int jpegenc_kernel_times(jpegenc_ctx* ctx, uint64_t launches[JPEGENC_N_KERNELS], double ms[JPEGENC_N_KERNELS],
                          int reset) {
     if (!ctx || !launches || !ms) return JPEGENC_E_BAD_ARG;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevGuard guard(ctx->device);
+    HIPCHK(ctx, guard.err);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (auto& ep : ctx->events) {
         float t = 0.f;

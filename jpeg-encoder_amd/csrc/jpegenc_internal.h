@@ -16,6 +16,15 @@ constexpr int kMaxMcuWords = 156;
 // Chunk stream slot in the workspace, in 32-bit words: worst case of 64 MCUs.
 constexpr int kSlotWords = kChunkMcus * kMaxMcuWords;  // 9984 words = 39,936 B
 
+// The workspace of one launch group, sized for `chunks` chunks.
+struct Workspace {
+    uint32_t* slots;       // [chunks + 1][kSlotWords]: the stuffing kernels read up to 1 KB past a chunk's stream
+    uint32_t* chunk_bits;  // [chunks]
+    uint32_t* chunk_ff;    // [chunks]
+    uint64_t* bit_off;     // [chunks]
+    uint64_t* ff_off;      // [chunks]
+};
+
 // Huffman table, one 32-bit word per entry in global memory: (total_length << 27) | (code << size) with
 // total_length = code length + amplitude bits, 0 = nothing to emit.  The kernel keeps the two fields in
 // two LDS arrays (a word and a byte per entry), so a lookup needs no unpacking.

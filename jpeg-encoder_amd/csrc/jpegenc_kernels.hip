@@ -1164,6 +1164,10 @@ __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_write(StuffParams p,
                     if (b == 0xFFu) seq <<= 8;
                 }
                 for (uint32_t k = 0; k < head; ++k) stage[k] = (uint8_t)(seq >> (8 * (head - 1 - k)));
+            } else if (head != 0) {
+                // a one-chunk segment whose first word begins in the segment before it: those bytes are the
+                // neighbour's and read as zero here, like the ones it leaves zero in memory
+                for (uint32_t k = 0; k < head; ++k) stage[k] = 0;
             }
             uint32_t f = fill;
             if (rem) {

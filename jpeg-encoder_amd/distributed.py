@@ -165,3 +165,56 @@ def encode_monolithic(band, device=None, root=0, group=None):
     result = dict(n_full_words=int(last[2]), total_bits_unstuffed=int(last[3]), total_bytes_stuffed=int(last[4]),
                   tail_word=int(last[5]), tail_bits=int(last[6]), eof_partial_ready=int(last[7]), status=int(last[8]))
     return out, result
+
+
+# ---- the HIP path behind the functions above: device-resident images, torch tensors in and out ------------
+def hip_stripe_coder(enc, image, n_stripes, bytes_per_pixel_room=3.0):
+    """Returns encode_stripe(s) for `encode_striped_image`: stripe s of `image` (an (h, w, 3) uint8 torch
+    tensor on the encoder's GPU; h a multiple of 8 * n_stripes) coded by `enc` (a JpegTop whose stream is
+    torch's current one) as jpeg_top would code that sub-image after rst.  The words stay on the GPU."""
+    import torch
+    from .encoder import RESULT_DTYPE
+    h, w, _ = image.shape
+    rows = h // n_stripes
+    assert rows * n_stripes == h and rows % 8 == 0 and image.is_contiguous() and image.dtype == torch.uint8
+    cap = int(w * rows * bytes_per_pixel_room) // 4 + 2
+
+    def encode_stripe(s):
+        words = torch.zeros(cap, dtype=torch.int32, device=image.device)
+        res_d = torch.zeros(32, dtype=torch.uint8, device=image.device)
+        enc.encode_batch_device(image.data_ptr() + s * rows * w * 3, 1, w, rows, w * 3, rows * w * 3,
+                                words.data_ptr(), cap, res_d.data_ptr())
+        enc.synchronize()
+        res = res_d.cpu().numpy().view(RESULT_DTYPE)[0]
+        if int(res["status"]) != 0:
+            raise RuntimeError("stripe %d does not fit %d words" % (s, cap))
+        n = int(res["n_full_words"]) + (1 if res["tail_bits"] else 0)
+        return words[:n], res
+
+    return encode_stripe
+
+
+class HipBand:
+    """Band coder for `encode_monolithic` on the HIP path: rows [lo, hi) of `image` (an (h, w, 3) uint8 torch
+    tensor on the encoder's GPU) through the three segment calls of the C ABI; the words stay on the GPU."""
+
+    def __init__(self, enc, image, lo, hi, bytes_per_pixel_room=3.0):
+        import torch
+        assert image.is_contiguous() and image.dtype == torch.uint8 and lo % 8 == 0 and hi % 8 == 0
+        self.enc, self.image, self.lo, self.hi = enc, image, lo, hi
+        self.w = image.shape[1]
+        self.cap = int(self.w * (hi - lo) * bytes_per_pixel_room) // 4 + 4
+
+    def encode(self):
+        return self.enc.segment_encode_device(self.image.data_ptr() + self.lo * self.w * 3, self.w, self.hi - self.lo,
+                                              self.w * 3, self.lo > 0)
+
+    def count(self, bit_offset, prev_tail8):
+        return self.enc.segment_count(bit_offset, prev_tail8)
+
+    def write(self, ff_offset, is_last):
+        import torch
+        words = torch.zeros(self.cap, dtype=torch.int32, device=self.image.device)
+        torch.cuda.current_stream(self.image.device).synchronize()
+        first_word, n_words, result = self.enc.segment_write_device(ff_offset, is_last, words.data_ptr(), self.cap)
+        return first_word, words[:n_words], result

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "jpegenc_max_words", "jpegenc_encode_rgb8", "jpegenc_encode_batch", "jpegenc_encode_stripes", "jpegenc_reset",
     "jpegenc_push_pixel", "jpegenc_push_pixels", "jpegenc_end_of_file", "jpegenc_read_words",
     "jpegenc_words_to_bytes", "jpegenc_set_profiling", "jpegenc_kernel_times", "jpegenc_kernel_name",
-    "jpegenc_set_workspace_limit", "jpegenc_segment_encode", "jpegenc_segment_count",
+    "jpegenc_set_workspace_limit", "jpegenc_reserve", "jpegenc_segment_encode", "jpegenc_segment_count",
     "jpegenc_segment_write", "jpegenc_strerror", "jpegenc_last_error", "jpegenc_version",
 ]
 
@@ -95,6 +95,7 @@ def load_library(path=None):
     L.jpegenc_kernel_name.argtypes = [i32]
     L.jpegenc_kernel_name.restype = C.c_char_p
     L.jpegenc_set_workspace_limit.argtypes = [vp, sz]
+    L.jpegenc_reserve.argtypes = [vp, i32, i32, i32]
     u64 = C.c_uint64
     L.jpegenc_segment_encode.argtypes = [vp, vp, i32, i32, C.c_ssize_t, u32, C.POINTER(u64), C.POINTER(u32)]
     L.jpegenc_segment_count.argtypes = [vp, u64, u32, C.POINTER(u64)]
@@ -174,6 +175,10 @@ class JpegTop:
     def set_workspace_limit(self, nbytes):
         self._check(self.lib.jpegenc_set_workspace_limit(self._ctx, int(nbytes)))
 
+    def reserve(self, n_images, w, h):
+        """Grows the workspace now, so that device-pointer calls of up to this size only enqueue work."""
+        self._check(self.lib.jpegenc_reserve(self._ctx, int(n_images), int(w), int(h)))
+
     def set_profiling(self, on):
         self._check(self.lib.jpegenc_set_profiling(self._ctx, int(bool(on))))
 
@@ -226,7 +231,12 @@ class JpegTop:
                                                   DEVICE_PTRS, C.c_void_p(words_ptr), cap_words,
                                                   C.c_void_p(results_ptr)))
 
-    # -- port-level protocol -----------------------------------------------------------------
+    def encode_stripes_device(self, rgb_ptr, w, h, stride, n_stripes, words_ptr, cap_words_per_stripe, results_ptr):
+        """jpegenc_encode_stripes on device addresses (ints); only enqueues work."""
+        self._check(self.lib.jpegenc_encode_stripes(self._ctx, C.c_void_p(rgb_ptr), w, h, stride, n_stripes,
+                                                    DEVICE_PTRS, C.c_void_p(words_ptr), cap_words_per_stripe,
+                                                    C.c_void_p(results_ptr)))
+
     # -- one stream from consecutive bands of an image -----------------------------------------
     def segment_encode(self, image, row0, rows):
         """Codes rows [row0, row0 + rows) of the (h, w, 3) uint8 host array `image` as a band of the
@@ -271,6 +281,22 @@ class JpegTop:
             rec = rec[0]
         return int(fw.value), words[:int(nw.value)], rec
 
+    def segment_write_device(self, ff_offset, is_last, words_ptr, cap_words):
+        """Same with the words left in device memory at `words_ptr` (room for cap_words).  Returns
+        (first_word, n_words, result or None)."""
+        res = Result()
+        fw, nw = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.jpegenc_segment_write(self._ctx, int(ff_offset), int(bool(is_last)), DEVICE_PTRS,
+                                                   C.c_void_p(words_ptr), cap_words, C.byref(fw), C.byref(nw),
+                                                   C.byref(res)))
+        rec = None
+        if is_last:
+            rec = np.zeros(1, dtype=RESULT_DTYPE)
+            C.memmove(rec.ctypes.data, C.byref(res), 32)
+            rec = rec[0]
+        return int(fw.value), int(nw.value), rec
+
+    # -- port-level protocol -----------------------------------------------------------------
     def reset(self):
         self._check(self.lib.jpegenc_reset(self._ctx))
 

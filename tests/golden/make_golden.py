@@ -40,9 +40,17 @@ def cases():
     yield "natural_24x40", natural_like(24, 40, 11), {}
     yield "binary_noise_16x72", rng.choice(np.array([0, 255], dtype=np.uint8), size=(16, 72, 3)), {}
     yield "random_8x520", rng.integers(0, 256, (8, 520, 3), dtype=np.uint8), {}
-    yield "random_32x32_sparse_quant", rng.integers(0, 256, (32, 32, 3), dtype=np.uint8), {"qtabs": sparse_q}
-    yield "random_32x32_sparse_quant_cbfix", rng.integers(0, 256, (32, 32, 3), dtype=np.uint8), \
-        {"qtabs": sparse_q, "cb_6d64": False}
+    # One image under both settings of the cb_huff 6'd64 switch; the two streams must differ (checked in main).
+    # The table keeps zig-zag positions 31 and 51 (entries 35 and 45) and little else, so that Cb blocks have
+    # the 16th zero of a run at position 47 with a coefficient still to come: the case the literal decides.
+    q3_tab = [[255] * 64 for _ in range(3)]
+    for c in range(3):
+        for i in (0, 1, 8, 35, 45):
+            q3_tab[c][i] = 2 + c
+    q3 = rng.integers(0, 256, (32, 32, 3), dtype=np.uint8)
+    yield "random_32x32_sparse_quant", q3, {"qtabs": q3_tab}
+    yield "random_32x32_sparse_quant_cbfix", q3, {"qtabs": q3_tab, "cb_6d64": False}
+    yield "random_32x32_sparse_quant_b", rng.integers(0, 256, (32, 32, 3), dtype=np.uint8), {"qtabs": sparse_q}
     yield "natural_16x16_quant", natural_like(16, 16, 12), {"qtabs": [[3] * 64, [7] * 64, [16] * 64]}
 
 
@@ -59,6 +67,11 @@ def main():
                         n_full_words=int(res.n_full_words), tail_bits=int(res.tail_bits),
                         tail_word=int(res.tail_word), total_bits_unstuffed=int(res.total_bits_unstuffed),
                         total_bytes_stuffed=int(res.total_bytes_stuffed)))
+    by_name = {v["name"]: v for v in out}
+    a, b = by_name["random_32x32_sparse_quant"], by_name["random_32x32_sparse_quant_cbfix"]
+    assert a["rgb_hex"] == b["rgb_hex"] and a["words_hex"] != b["words_hex"], "the Q3 pair must differ by the switch alone"
+    a, b = by_name["pure_blue_8x16_wrap"], by_name["pure_blue_8x16_nowrap"]
+    assert a["rgb_hex"] == b["rgb_hex"] and a["words_hex"] != b["words_hex"]
     with open(os.path.join(HERE, "vectors.json"), "w") as f:
         json.dump(out, f, indent=0)
     print("wrote %d vectors, %d bytes" % (len(out), os.path.getsize(os.path.join(HERE, "vectors.json"))))

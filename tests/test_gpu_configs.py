@@ -1,0 +1,267 @@
+"""GPU tests at the sizes of the named configurations: a device-resident batch of 1080p frames (the
+per-GPU share of the sharded 8192-frame configuration), a 16384 x 16384 image as eight restart-interval
+stripes, the multi-GPU glue driven by the HIP path (one rank: the exchange degenerates, the code path is
+the one every rank runs), two streams sharing one context, and the HIP stream inside a JFIF container.
+Every comparison is word for word against the CPU oracle unless it says otherwise."""
+import io
+import socket
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import load_pkg, natural_like
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def same_as_oracle(words, res, rgb, cfg=None):
+    want, r = O.encode(rgb, cfg)
+    got = (int(res["n_full_words"]), int(res["tail_bits"]), int(res["tail_word"]), int(res["total_bits_unstuffed"]),
+           int(res["total_bytes_stuffed"]), int(res["status"]))
+    assert got == (r.n_full_words, r.tail_bits, r.tail_word, r.total_bits_unstuffed, r.total_bytes_stuffed, 0)
+    assert len(words) == len(want) and np.array_equal(words, want)
+
+
+def no_unstuffed_ff(words, res):
+    a = np.frombuffer(np.asarray(words, dtype=np.uint32).astype(">u4").tobytes()[:int(res["total_bytes_stuffed"])],
+                      dtype=np.uint8)
+    ff = np.nonzero(a[:-1] == 0xFF)[0]
+    return bool((a[ff + 1] == 0).all())
+
+
+def test_1080p_batch_of_64_distinct_frames():
+    """64 device-resident 1080p frames in one jpegenc_encode_batch call: 60 distinct natural-like frames and
+    4 repeats.  Ten frames word for word against the oracle; all of them by the properties that do not need
+    it (status, stuffing, repeats give identical streams wherever they sit in the batch)."""
+    pkg = load_pkg()
+    dev = torch.device("cuda:0")
+    h, w, n = 1080, 1920, 64
+    frames = torch.empty((n, h, w, 3), dtype=torch.uint8, device=dev)
+    for s in range(0, 60, 12):
+        frames[s:s + 12] = pkg.synth.natural_like_torch(12, h, w, 4000 + s, dev)
+    frames[60:64] = frames[torch.tensor([0, 17, 33, 59], device=dev)]
+    cap = w * h * 3 // 4
+    d_words = torch.zeros((n, cap), dtype=torch.int32, device=dev)
+    d_res = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
+    with pkg.JpegTop(stream=torch.cuda.current_stream().cuda_stream) as e:
+        e.reserve(n, w, h)
+        e.encode_batch_device(frames.data_ptr(), n, w, h, w * 3, h * w * 3, d_words.data_ptr(), cap, d_res.data_ptr())
+        torch.cuda.synchronize()
+    res = d_res.cpu().numpy().view(pkg.RESULT_DTYPE).reshape(n)
+    assert (res["status"] == 0).all()
+    counts = res["n_full_words"].astype(np.int64) + (res["tail_bits"] != 0)
+    checked = [0, 1, 11, 12, 31, 32, 47, 59, 62, 63]
+    host = {i: frames[i].cpu().numpy() for i in checked}
+    got = {i: d_words[i, :int(counts[i])].cpu().numpy().view(np.uint32) for i in range(n)}
+    with ThreadPoolExecutor(8) as pool:  # the oracle releases the GIL inside its C call
+        list(pool.map(lambda i: same_as_oracle(got[i], res[i], host[i]), checked))
+    for i in range(n):
+        assert no_unstuffed_ff(got[i], res[i])
+    for i, j in zip((60, 61, 62, 63), (0, 17, 33, 59)):
+        assert res[i].tobytes() == res[j].tobytes() and np.array_equal(got[i], got[j])
+    sizes = {int(c) for c in counts[:60]}
+    assert len(sizes) > 50  # distinct frames really were distinct
+
+
+def test_16384_square_image_as_eight_stripes():
+    """A 16384 x 16384 image through jpegenc_encode_stripes: every one of the eight 16384 x 2048 stripes must be
+    the stream jpeg_top gives for that sub-image after rst."""
+    pkg = load_pkg()
+    dev = torch.device("cuda:0")
+    n, stripes = 16384, 8
+    rows = n // stripes
+    img = torch.cat([pkg.synth.natural_like_torch(1, rows, n, 7 + k, dev)[0] for k in range(stripes)])
+    # a block of pure noise across the boundary of stripes 2 and 3: long strings and 0xFF bytes at a restart
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    img[3 * rows - 64:3 * rows + 64, 1000:3000] = torch.randint(0, 256, (128, 2000, 3), generator=g, device=dev,
+                                                                 dtype=torch.uint8)
+    cap = n * rows * 3 // 4
+    d_words = torch.zeros((stripes, cap), dtype=torch.int32, device=dev)
+    d_res = torch.zeros((stripes, 32), dtype=torch.uint8, device=dev)
+    with pkg.JpegTop(stream=torch.cuda.current_stream().cuda_stream) as e:
+        e.encode_stripes_device(img.data_ptr(), n, n, n * 3, stripes, d_words.data_ptr(), cap, d_res.data_ptr())
+        torch.cuda.synchronize()
+    res = d_res.cpu().numpy().view(pkg.RESULT_DTYPE).reshape(stripes)
+    assert (res["status"] == 0).all()
+    host = img.cpu().numpy()
+    del img
+
+    def check(s):
+        k = int(res[s]["n_full_words"]) + (1 if res[s]["tail_bits"] else 0)
+        same_as_oracle(d_words[s, :k].cpu().numpy().view(np.uint32), res[s], host[s * rows:(s + 1) * rows])
+
+    with ThreadPoolExecutor(8) as pool:
+        list(pool.map(check, range(stripes)))
+
+
+@pytest.fixture
+def one_rank_group():
+    """A process group of one rank on the GPU backend (RCCL); the functions under test run the code every
+    rank of a multi-GPU job runs, with the exchange reduced to rank 0 talking to itself."""
+    import torch.distributed as dist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        yield dist
+    finally:
+        dist.destroy_process_group()
+
+
+def test_stripe_gather_and_band_merge_fed_by_the_hip_path(one_rank_group):
+    pkg = load_pkg()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(12)
+    img = natural_like(512, 1024, 21)
+    img[200:280, 300:700] = rng.integers(0, 256, (80, 400, 3), dtype=np.uint8)
+    d_img = torch.from_numpy(img).to(dev)
+    with pkg.JpegTop(stream=torch.cuda.current_stream().cuda_stream) as e:
+        # restart-interval stripes: table + payload on the root
+        n_stripes = 8
+        table, payload = pkg.distributed.encode_striped_image(pkg.distributed.hip_stripe_coder(e, d_img, n_stripes),
+                                                              n_stripes, device=dev)
+        payload = payload.cpu().numpy().view(np.uint32)
+        off = 0
+        for s in range(n_stripes):
+            want, r = O.encode(img[64 * s:64 * (s + 1)])
+            assert table[s, 0] == off
+            assert tuple(table[s, 1:4]) == (r.n_full_words, r.tail_bits, r.tail_word)
+            assert table[s, 6] == len(want) and np.array_equal(payload[off:off + len(want)], want)
+            off += len(want)
+        assert off == len(payload)
+        # one stream: the band coder is the HIP segment path, the words never leave the GPU before the merge
+        lo, hi = pkg.distributed.band_rows(img.shape[0], 0, 1)
+        words, res = pkg.distributed.encode_monolithic(pkg.distributed.HipBand(e, d_img, lo, hi), device=dev)
+        want, r = O.encode(img)
+        words = words.cpu().numpy().view(np.uint32)
+        assert (res["n_full_words"], res["tail_bits"], res["tail_word"]) == (r.n_full_words, r.tail_bits, r.tail_word)
+        assert np.array_equal(words[:len(want)], want) and not words[len(want):].any()
+
+
+def test_two_streams_share_one_context():
+    """Device-pointer calls only enqueue work and all calls of a context share its workspace: when the caller
+    moves the context to another stream, the batch still running on the first stream must finish with the
+    workspace before the second batch overwrites it."""
+    pkg = load_pkg()
+    dev = torch.device("cuda:0")
+    h, w, n = 1080, 1920, 24
+    a = pkg.synth.natural_like_torch(n, h, w, 900, dev)
+    b = pkg.synth.natural_like_torch(n, h, w, 901, dev)
+    cap = w * h * 3 // 4
+    out = [torch.zeros((n, cap), dtype=torch.int32, device=dev) for _ in range(2)]
+    res = [torch.zeros((n, 32), dtype=torch.uint8, device=dev) for _ in range(2)]
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    torch.cuda.synchronize()
+    with pkg.JpegTop() as e:
+        e.reserve(n, w, h)
+        for rep in range(3):  # back to back, never a host synchronisation in between
+            e.set_stream(s1.cuda_stream)
+            e.encode_batch_device(a.data_ptr(), n, w, h, w * 3, h * w * 3, out[0].data_ptr(), cap, res[0].data_ptr())
+            e.set_stream(s2.cuda_stream)
+            e.encode_batch_device(b.data_ptr(), n, w, h, w * 3, h * w * 3, out[1].data_ptr(), cap, res[1].data_ptr())
+        torch.cuda.synchronize()
+    for frames, o, r in ((a, out[0], res[0]), (b, out[1], res[1])):
+        rr = r.cpu().numpy().view(pkg.RESULT_DTYPE).reshape(n)
+        assert (rr["status"] == 0).all()
+        for i in (0, n // 2, n - 1):
+            k = int(rr[i]["n_full_words"]) + (1 if rr[i]["tail_bits"] else 0)
+            same_as_oracle(o[i, :k].cpu().numpy().view(np.uint32), rr[i], frames[i].cpu().numpy())
+        # the frames between them: equal to a second encode done alone
+    with pkg.JpegTop(stream=torch.cuda.current_stream().cuda_stream) as e:
+        for frames, o in ((a, out[0]), (b, out[1])):
+            again = torch.zeros_like(o)
+            r2 = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
+            e.encode_batch_device(frames.data_ptr(), n, w, h, w * 3, h * w * 3, again.data_ptr(), cap, r2.data_ptr())
+            torch.cuda.synchronize()
+            rr = r2.cpu().numpy().view(pkg.RESULT_DTYPE).reshape(n)
+            for i in range(n):
+                k = int(rr[i]["n_full_words"]) + (1 if rr[i]["tail_bits"] else 0)
+                assert torch.equal(again[i, :k], o[i, :k])
+
+
+def test_hip_stream_in_a_jfif_container_decodes():
+    """The GPU's words wrapped in JFIF headers decode with libjpeg (Pillow) to the input: default tables
+    nearly lossless, a quantised table at its expected quality, an odd size through the padding extension."""
+    Image = pytest.importorskip("PIL.Image")
+    pkg = load_pkg()
+
+    def psnr(x, y):
+        mse = np.mean((x.astype(np.float64) - y.astype(np.float64)) ** 2)
+        return 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+
+    def decode(jpg):
+        return np.asarray(Image.open(io.BytesIO(jpg)).convert("RGB"))
+
+    rgb = natural_like(136, 200, 4)
+    with pkg.JpegTop() as e:
+        words, res = e.encode(rgb)
+        out = decode(pkg.jfif.wrap_jfif(words, int(res["n_full_words"]), int(res["tail_bits"]), 200, 136))
+        assert out.shape == rgb.shape and psnr(out, rgb) > 40.0
+        odd = rgb[:101, :77]
+        words, res = e.encode(odd, pad_edges=True)
+        out = decode(pkg.jfif.wrap_jfif(words, int(res["n_full_words"]), int(res["tail_bits"]), 77, 101))
+        assert out.shape == odd.shape and psnr(out, odd) > 40.0
+    qt = [np.full(64, 8), np.full(64, 16), np.full(64, 16)]
+    with pkg.JpegTop(qtabs=qt) as e:
+        words, res = e.encode(rgb)
+        out = decode(pkg.jfif.wrap_jfif(words, int(res["n_full_words"]), int(res["tail_bits"]), 200, 136, qtabs=qt))
+        assert psnr(out, rgb) > 28.0
+    conv = np.array([[32 if b >= 3 else 2 for b in range(8)] for a in range(8)]).reshape(64)
+    with pkg.JpegTop(qtabs=[conv] * 3, quant_index_order=1) as e:
+        words, res = e.encode(rgb)
+        good = decode(pkg.jfif.wrap_jfif(words, int(res["n_full_words"]), int(res["tail_bits"]), 200, 136,
+                                         qtabs=[conv] * 3, quant_index_order=1))
+        assert psnr(good, rgb) > 28.0
+
+
+def test_segment_state_is_dropped_by_other_calls_and_one_chunk_last_band():
+    """An encode call between the segment steps discards the band's chunk streams: the later steps must say
+    so.  And a last band of a single chunk whose first word begins in the band before it reports as
+    tail_word its own bytes only (the neighbour's read as zero)."""
+    pkg = load_pkg()
+    img = np.random.default_rng(72).integers(0, 256, (32, 64, 3), dtype=np.uint8)
+    with pkg.JpegTop() as e:
+        e.segment_encode(img, 0, 32)
+        e.encode(img)
+        with pytest.raises(pkg.JpegEncError) as err:
+            e.segment_count(0, 0)
+        assert err.value.code == pkg.E_STATE
+        e.segment_encode(img, 0, 32)
+        e.segment_count(0, 0)
+        e.encode(img)
+        with pytest.raises(pkg.JpegEncError) as err:
+            e.segment_write(0, True, 4096)
+        assert err.value.code == pkg.E_STATE
+    # an image one MCU wide, bands of one MCU: every band is a single chunk, and the flat last two MCUs make the
+    # last band 18 bits that mostly sit inside the word the band before it ends in
+    for seed in range(8):
+        img = natural_like(24, 8, 300 + seed)
+        img[8:] = img[8, 0]
+        want, r = O.encode(img)
+        bands = [pkg.JpegTop() for _ in range(3)]
+        try:
+            info = [b.segment_encode(img, 8 * i, 8) for i, b in enumerate(bands)]
+            offs = np.concatenate([[0], np.cumsum([i[0] for i in info])])
+            ffs = [b.segment_count(int(offs[i]), info[i - 1][1] if i else 0) for i, b in enumerate(bands)]
+            ffo = np.concatenate([[0], np.cumsum(ffs)])
+            merged = np.zeros(len(want) + 4, dtype=np.uint32)
+            parts = []
+            for i, b in enumerate(bands):
+                fw, words, res = b.segment_write(int(ffo[i]), i == 2, 4096)
+                merged[fw:fw + len(words)] |= words
+                parts.append((fw, words))
+            assert np.array_equal(merged[:len(want)], want)
+            if int(res["tail_bits"]):
+                fw, words = parts[-1]
+                assert int(res["tail_word"]) == int(words[int(res["n_full_words"]) - fw])  # its own bytes only
+        finally:
+            for b in bands:
+                b.close()

@@ -159,13 +159,22 @@ def test_quirk_switches_and_quant_tables():
         sparse[c][rng.integers(0, 64, 6)] = rng.integers(1, 8, 6)
     cases = [dict(), dict(rgb_wrap=False), dict(cb_6d64=False), dict(qtabs=qt), dict(qtabs=sparse),
              dict(qtabs=sparse, cb_6d64=False), dict(qtabs=qt, quant_index_order=1)]
-    for kw in cases:
+    streams = {}
+    for k, kw in enumerate(cases):
         with pkg.JpegTop(**kw) as e:
             cfg = O.default_config(qtabs=kw.get("qtabs"), rgb_wrap=kw.get("rgb_wrap", True),
                                    cb_6d64=kw.get("cb_6d64", True), quant_index_order=kw.get("quant_index_order", 0))
-            for img in (rgb, noise):
+            for name, img in (("rgb", rgb), ("noise", noise)):
                 words, res = e.encode(img)
                 assert_same(words, res, img, cfg)
+                streams[k, name] = words
+    # every switch must matter on at least one of the images, or the comparisons above prove nothing about it
+    def differ(a, b):
+        return any(not np.array_equal(streams[a, n], streams[b, n]) for n in ("rgb", "noise"))
+    assert differ(0, 1), "rgb_wrap changed nothing"
+    assert differ(0, 2), "cb_6d64 changed nothing at the default tables"
+    assert differ(4, 5), "cb_6d64 changed nothing at the sparse tables"
+    assert differ(3, 6), "quant_index_order changed nothing"
 
 
 def test_batch_and_stripes(enc):
