@@ -32,6 +32,7 @@ extern "C" {
 #define JPEGENC_E_UNSUPPORTED (-4)
 #define JPEGENC_E_NOMEM (-5)
 #define JPEGENC_E_STATE (-6) /* calls out of order: push/end_of_file protocol, segment calls */
+#define JPEGENC_E_LIMIT (-7) /* jpegenc_encode_batch_noalloc: the call exceeds JPEGENC_NOALLOC_MAX_CHUNKS */
 
 /* flags for the encode calls */
 #define JPEGENC_HOST_PTRS 0u   /* rgb / words_out / results are host memory (copied, call blocks) */
@@ -114,6 +115,25 @@ int jpegenc_encode_rgb8(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int h, ptrd
 int jpegenc_encode_batch(jpegenc_ctx* ctx, const uint8_t* rgb, int n_images, int w, int h, ptrdiff_t stride,
                          ptrdiff_t image_stride, uint32_t flags, uint32_t* words_out, size_t cap_words_per_image,
                          jpegenc_result* results);
+
+/* jpegenc_encode_batch for callers that cannot allocate device memory: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference (hardware has no
+ * allocator).  Device pointers only (rgb, words_out and results are device memory on the context's device);
+ * same kernels, same output and the same per-image status as jpegenc_encode_batch with
+ * JPEGENC_DEVICE_PTRS; only enqueues work on the context's stream.  It calls no hipMalloc/hipFree and no
+ * other allocating routine (kernel timing, which creates events, is off for these calls): the intermediate
+ * chunk streams live in a fixed array inside the library's code object, JPEGENC_NOALLOC_MAX_CHUNKS chunks
+ * of 64 blocks (81.9 MB that every GPU the library runs on holds until the process ends).  A call needs
+ * n_images * ceil((w/8) * (h/8) / 64) chunks -- one 3840x2160 frame is 2025, four 1080p frames are 2028 --
+ * and is refused with JPEGENC_E_LIMIT (nothing enqueued) beyond that.  w and h must be multiples of 8
+ * (no JPEGENC_PAD_EDGES: padding needs a staging buffer).
+ * All calls on one GPU, from every context, share that GPU's array: calls that overlap in time on one GPU
+ * (two streams, two contexts, two threads) race.  The array keeps the last call's contents; the kernels
+ * rewrite every part they later read, so nothing has to be cleared between calls. */
+#define JPEGENC_NOALLOC_MAX_CHUNKS 2048
+int jpegenc_encode_batch_noalloc(jpegenc_ctx* ctx, const uint8_t* rgb, int n_images, int w, int h, ptrdiff_t stride,
+                                 ptrdiff_t image_stride, uint32_t* words_out, size_t cap_words_per_image,
+                                 jpegenc_result* results);
 
 /* One image cut into n_stripes horizontal stripes of stripe_rows rows (a multiple of 8;
  * n_stripes*stripe_rows == h).  Every stripe is encoded exactly as jpeg_top would encode that

@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -104,6 +105,9 @@ struct jpegenc_ctx {
     // stream (jpegenc_set_stream) waits for it before it touches the workspace again.
     hipEvent_t ws_event = nullptr;
     bool ws_pending = false;
+
+    // jpegenc_encode_batch_noalloc: this device's copy of the library's static workspace
+    uint8_t* static_ws = nullptr;
 
     // segment API: what jpegenc_segment_encode left in the workspace
     bool seg_ready = false, seg_counted = false;
@@ -371,6 +375,25 @@ int encode_device(jpegenc_ctx* ctx, const uint8_t* rgb, int n_images, int w, int
     return workspace_used(ctx);
 }
 
+// Device address of the library's static workspace on `device`, which must be the current device.  Looked up
+// once per device, at the first jpegenc_create on it.
+hipError_t static_workspace_of(int device, uint8_t** out) {
+    constexpr int kMaxDevices = 64;
+    static std::mutex mu;
+    static uint8_t* known[kMaxDevices] = {};
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!known[device]) {
+        void* p = nullptr;
+        const hipError_t e = static_workspace(&p);
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        known[device] = static_cast<uint8_t*>(p);
+    }
+    *out = known[device];
+    return hipSuccess;
+}
+
 int check_dims(const void* rgb, int n, int w, int h, ptrdiff_t stride, const void* words, const void* results,
                bool pad_edges = false) {
     if (!rgb || !words || !results) return JPEGENC_E_BAD_ARG;
@@ -460,6 +483,8 @@ int jpegenc_create(jpegenc_ctx** out, const jpegenc_config* cfg) {
     }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ws_event, hipEventDisableTiming);
+    // the address of the static workspace on this device (every device holds its own copy at its own address)
+    if (e == hipSuccess) e = static_workspace_of(ctx->device, &ctx->static_ws);
     if (e != hipSuccess) {
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
         delete ctx;
@@ -617,6 +642,40 @@ int jpegenc_reserve(jpegenc_ctx* ctx, int n_images, int w, int h) {
     if (rc != JPEGENC_OK) return rc;
     ctx->seg_ready = ctx->seg_counted = false;  // growing the workspace discards a segment's chunk streams
     return reserve_for_plan(ctx, &pl);
+}
+
+int jpegenc_encode_batch_noalloc(jpegenc_ctx* ctx, const uint8_t* rgb, int n_images, int w, int h, ptrdiff_t stride,
+                                 ptrdiff_t image_stride, uint32_t* words_out, size_t cap_words_per_image,
+                                 jpegenc_result* results) {
+    if (!ctx) return JPEGENC_E_BAD_ARG;
+    int rc = check_dims(rgb, n_images, w, h, stride, words_out, results);
+    if (rc != JPEGENC_OK) return rc;
+    if (cap_words_per_image == 0) return JPEGENC_E_BAD_ARG;
+    if (n_images > 1 && (image_stride < 0 ? -image_stride : image_stride) < stride * ptrdiff_t(h) && image_stride != 0)
+        return JPEGENC_E_BAD_ARG;
+    Plan pl;
+    rc = make_plan(ctx, n_images, w, h, &pl);
+    if (rc != JPEGENC_OK) return rc;
+    if (uint64_t(n_images) * pl.cpi > kStaticChunks) {
+        char buf[160];
+        std::snprintf(buf, sizeof buf, "jpegenc_encode_batch_noalloc: %llu chunks of 64 blocks needed, the static workspace holds %llu",
+                      (unsigned long long)(uint64_t(n_images) * pl.cpi), (unsigned long long)kStaticChunks);
+        ctx->last_error = buf;
+        return JPEGENC_E_LIMIT;
+    }
+    DevGuard guard(ctx->device);
+    HIPCHK(ctx, guard.err);
+    // the parts of the static workspace (device addresses derived from the looked-up base, never from the symbol)
+    uint8_t* const base = ctx->static_ws;
+    Workspace ws;
+    ws.slots = reinterpret_cast<uint32_t*>(base);
+    ws.bit_off = reinterpret_cast<uint64_t*>(base + kStaticSlotBytes);
+    ws.ff_off = ws.bit_off + kStaticChunks;
+    ws.chunk_bits = reinterpret_cast<uint32_t*>(ws.ff_off + kStaticChunks);
+    ws.chunk_ff = ws.chunk_bits + kStaticChunks;
+    // one launch group; no events are created (timed = false), nothing is allocated, staged or synchronised
+    return run_group(ctx, ws, false, pl, rgb, uint32_t(n_images), stride, image_stride,
+                     pointer_align(rgb, stride, image_stride, n_images, h), words_out, cap_words_per_image, results);
 }
 
 int jpegenc_encode_rgb8(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int h, ptrdiff_t stride, uint32_t flags,
@@ -910,6 +969,7 @@ const char* jpegenc_strerror(int code) {
         case JPEGENC_E_UNSUPPORTED: return "unsupported configuration";
         case JPEGENC_E_NOMEM: return "out of memory";
         case JPEGENC_E_STATE: return "calls out of order (port protocol or segment calls)";
+        case JPEGENC_E_LIMIT: return "call exceeds the static workspace of jpegenc_encode_batch_noalloc";
         default: return "unknown error";
     }
 }

@@ -25,6 +25,15 @@ struct Workspace {
     uint64_t* ff_off;      // [chunks]
 };
 
+// Static workspace of jpegenc_encode_batch_noalloc: room for JPEGENC_NOALLOC_MAX_CHUNKS chunks, laid out as
+// slots | bit_off | ff_off | chunk_bits | chunk_ff (every part starts a multiple of 256 bytes into it).
+constexpr size_t kStaticChunks = JPEGENC_NOALLOC_MAX_CHUNKS;
+constexpr size_t kStaticSlotBytes = (kStaticChunks + 1) * size_t(kSlotWords) * 4;
+static_assert(kStaticSlotBytes % 256 == 0 && kStaticChunks % 64 == 0, "the parts stay 256-byte aligned");
+constexpr size_t kStaticWsBytes = kStaticSlotBytes + kStaticChunks * (8 + 8 + 4 + 4);
+// Device address, on the current device, of that workspace (defined beside the array in jpegenc_kernels.hip).
+hipError_t static_workspace(void** ptr);
+
 // Huffman table, one 32-bit word per entry in global memory: (total_length << 27) | (code << size) with
 // total_length = code length + amplitude bits, 0 = nothing to emit.  The kernel keeps the two fields in
 // two LDS arrays (a word and a byte per entry), so a lookup needs no unpacking.

@@ -1231,6 +1231,17 @@ hipError_t launch_pad_edges(const uint8_t* src, int64_t stride, int64_t image_st
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Workspace of jpegenc_encode_batch_noalloc: one array per device, part of the code object, held for as long
+// as the library stays loaded.  On the host the array's name is only a handle for hipGetSymbolAddress; what
+// kernels, memsets and copies need is the device address that static_workspace() looks up.
+// ------------------------------------------------------------------------------------------------
+static __device__ __align__(256) uint8_t scratch[kStaticWsBytes];
+
+hipError_t static_workspace(void** ptr) {
+    return hipGetSymbolAddress(ptr, HIP_SYMBOL(scratch));  // the address on the current device
+}
+
 #endif  // !JPEGENC_TU_QUANT
 
 // ------------------------------------------------------------------------------------------------

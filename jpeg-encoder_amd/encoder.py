@@ -15,7 +15,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libjpegenc.so")
 
-OK, E_BAD_ARG, E_TOO_SMALL, E_HIP, E_UNSUPPORTED, E_NOMEM, E_STATE = 0, -1, -2, -3, -4, -5, -6
+OK, E_BAD_ARG, E_TOO_SMALL, E_HIP, E_UNSUPPORTED, E_NOMEM, E_STATE, E_LIMIT = 0, -1, -2, -3, -4, -5, -6, -7
+NOALLOC_MAX_CHUNKS = 2048
 HOST_PTRS, DEVICE_PTRS = 0, 1
 PAD_EDGES = 4
 SEG_CONTINUES = 2
@@ -24,7 +25,8 @@ N_KERNELS = 4
 # every symbol include/jpegenc.h declares
 ABI_SYMBOLS = [
     "jpegenc_default_config", "jpegenc_create", "jpegenc_destroy", "jpegenc_set_stream", "jpegenc_synchronize",
-    "jpegenc_max_words", "jpegenc_encode_rgb8", "jpegenc_encode_batch", "jpegenc_encode_stripes", "jpegenc_reset",
+    "jpegenc_max_words", "jpegenc_encode_rgb8", "jpegenc_encode_batch", "jpegenc_encode_batch_noalloc",
+    "jpegenc_encode_stripes", "jpegenc_reset",
     "jpegenc_push_pixel", "jpegenc_push_pixels", "jpegenc_end_of_file", "jpegenc_read_words",
     "jpegenc_words_to_bytes", "jpegenc_set_profiling", "jpegenc_kernel_times", "jpegenc_kernel_name",
     "jpegenc_set_workspace_limit", "jpegenc_reserve", "jpegenc_segment_encode", "jpegenc_segment_count",
@@ -83,6 +85,7 @@ def load_library(path=None):
     L.jpegenc_max_words.restype = sz
     L.jpegenc_encode_rgb8.argtypes = [vp, vp, i32, i32, C.c_ssize_t, u32, vp, sz, vp]
     L.jpegenc_encode_batch.argtypes = [vp, vp, i32, i32, i32, C.c_ssize_t, C.c_ssize_t, u32, vp, sz, vp]
+    L.jpegenc_encode_batch_noalloc.argtypes = [vp, vp, i32, i32, i32, C.c_ssize_t, C.c_ssize_t, vp, sz, vp]
     L.jpegenc_encode_stripes.argtypes = [vp, vp, i32, i32, C.c_ssize_t, i32, u32, vp, sz, vp]
     L.jpegenc_reset.argtypes = [vp]
     L.jpegenc_push_pixel.argtypes = [vp, u32]
@@ -230,6 +233,12 @@ class JpegTop:
         self._check(self.lib.jpegenc_encode_batch(self._ctx, C.c_void_p(rgb_ptr), n, w, h, stride, image_stride,
                                                   DEVICE_PTRS, C.c_void_p(words_ptr), cap_words,
                                                   C.c_void_p(results_ptr)))
+
+    def encode_batch_noalloc(self, rgb_ptr, n, w, h, stride, image_stride, words_ptr, cap_words, results_ptr):
+        """jpegenc_encode_batch_noalloc: as encode_batch_device, with the library's static workspace (at most
+        NOALLOC_MAX_CHUNKS chunks of 64 blocks per call, JpegEncError with code E_LIMIT beyond)."""
+        self._check(self.lib.jpegenc_encode_batch_noalloc(self._ctx, C.c_void_p(rgb_ptr), n, w, h, stride, image_stride,
+                                                          C.c_void_p(words_ptr), cap_words, C.c_void_p(results_ptr)))
 
     def encode_stripes_device(self, rgb_ptr, w, h, stride, n_stripes, words_ptr, cap_words_per_stripe, results_ptr):
         """jpegenc_encode_stripes on device addresses (ints); only enqueues work."""

@@ -1,0 +1,70 @@
+"""The entry point that allocates nothing (jpegenc_encode_batch_noalloc, static workspace inside the
+library) against jpegenc_encode_batch on the same inputs: word for word, through the C ABI, twice in a
+row with the second input smaller (the static array still holds the first call's contents)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import load_pkg
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def run_both(pkg, e, frames, cap):
+    """Codes `frames` (n, h, w, 3 uint8 on the GPU) through both entry points; returns [(words, results)] * 2."""
+    n, h, w, _ = frames.shape
+    outs = []
+    for call in (e.encode_batch_device, e.encode_batch_noalloc):
+        d_words = torch.full((n, cap), 0x5A5A5A5A, dtype=torch.int32, device=frames.device)
+        d_res = torch.zeros((n, 32), dtype=torch.uint8, device=frames.device)
+        torch.cuda.synchronize()
+        call(frames.data_ptr(), n, w, h, w * 3, h * w * 3, d_words.data_ptr(), cap, d_res.data_ptr())
+        torch.cuda.synchronize()
+        outs.append((d_words.cpu().numpy().view(np.uint32), d_res.cpu().numpy().view(pkg.RESULT_DTYPE).reshape(n)))
+    return outs
+
+
+def test_noalloc_entry_point_matches_the_allocating_one():
+    pkg = load_pkg()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(77)
+    big = pkg.synth.natural_like_torch(3, 1080, 1920, 500, dev)           # 3 x 507 chunks
+    big[1, 300:500, 400:900] = torch.randint(0, 256, (200, 500, 3), generator=g, device=dev, dtype=torch.uint8)
+    small = torch.randint(0, 256, (2, 72, 136, 3), generator=g, device=dev, dtype=torch.uint8)  # noise: long strings
+    with pkg.JpegTop(stream=torch.cuda.current_stream().cuda_stream) as e:
+        for frames in (big, small):  # two calls in a row, the second smaller
+            n, h, w, _ = frames.shape
+            cap = pkg.max_words(w, h) // 2
+            (w_ref, r_ref), (w_new, r_new) = run_both(pkg, e, frames, cap)
+            assert (r_ref["status"] == 0).all()
+            assert r_new.tobytes() == r_ref.tobytes()
+            assert np.array_equal(w_new, w_ref)  # every word of the output buffers, written or not
+            # and the allocating entry point itself is right: one frame of each against the oracle
+            k = int(r_ref[n - 1]["n_full_words"]) + (1 if r_ref[n - 1]["tail_bits"] else 0)
+            want, r = O.encode(frames[n - 1].cpu().numpy())
+            assert np.array_equal(w_new[n - 1, :k], want) and int(r_new[n - 1]["tail_word"]) == r.tail_word
+        # too small an output buffer is reported per image, as by the allocating entry point
+        n, h, w, _ = small.shape
+        (w_ref, r_ref), (w_new, r_new) = run_both(pkg, e, small, 64)
+        assert (r_ref["status"] == pkg.E_TOO_SMALL).all() and r_new.tobytes() == r_ref.tobytes()
+        assert np.array_equal(w_new, w_ref)
+        # sizes beyond the static workspace are refused, nothing is enqueued
+        five = pkg.synth.natural_like_torch(5, 1080, 1920, 600, dev)  # 5 x 507 = 2535 > 2048 chunks
+        d_words = torch.zeros((5, 16), dtype=torch.int32, device=dev)
+        d_res = torch.zeros((5, 32), dtype=torch.uint8, device=dev)
+        with pytest.raises(pkg.JpegEncError) as err:
+            e.encode_batch_noalloc(five.data_ptr(), 5, 1920, 1080, 1920 * 3, 1080 * 1920 * 3, d_words.data_ptr(), 16,
+                                   d_res.data_ptr())
+        assert err.value.code == pkg.E_LIMIT
+        torch.cuda.synchronize()
+        assert not d_words.any() and not d_res.any()
+        # exactly at the limit: one 3840 x 2160 frame is 2025 chunks
+        uhd = pkg.synth.natural_like_torch(1, 2160, 3840, 601, dev)
+        (w_ref, r_ref), (w_new, r_new) = run_both(pkg, e, uhd, 3840 * 2160 * 3 // 4)
+        assert (r_ref["status"] == 0).all() and r_new.tobytes() == r_ref.tobytes() and np.array_equal(w_new, w_ref)
+    # a second context shares the device's array; used one after the other that is fine
+    with pkg.JpegTop(stream=torch.cuda.current_stream().cuda_stream, qtabs=[[4] * 64] * 3) as e2:
+        (w_ref, r_ref), (w_new, r_new) = run_both(pkg, e2, small, pkg.max_words(136, 72))
+        assert (r_ref["status"] == 0).all() and r_new.tobytes() == r_ref.tobytes() and np.array_equal(w_new, w_ref)
