@@ -5,9 +5,12 @@
 
 One process per GPU (for N > 1 the driver starts this file under torch.distributed.run).  A step is one
 pass of the hot path -- RGB frames resident in HBM in, stuffed JPEG scan words resident in HBM out --
-over this rank's batch of synthetic 1080p frames.  Weak scaling: every rank holds `--frames` frames
-(default 1024; 8 ranks = the 8192-frame configuration), sharded by image, no data-path collective.
-Rank 0 prints one JSON line.
+over this rank's batch of synthetic 1080p frames.  Weak scaling by default: every rank holds `--frames` frames
+(1024; 8 ranks = the 8192-frame configuration), sharded by image, no data-path collective;
+`--scaling strong --total-frames 8192` holds the 8192 frames fixed and gives rank r the contiguous range
+shard_range(8192, r, N).  `--mode stripes16k` / `--mode mono16k` time the single 16384 x 16384 image instead:
+restart-interval stripes gathered on rank 0, or one stream merged from one band per rank.
+Rank 0 prints one JSON line; the exit status is non-zero when any image failed or differs from the oracle.
 """
 import argparse
 import importlib
@@ -27,7 +30,11 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=1024, help="frames per GPU")
+    ap.add_argument("--frames", type=int, default=1024, help="frames per GPU (weak scaling)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--total-frames", type=int, default=8192, help="frames of the whole job (strong scaling)")
+    ap.add_argument("--mode", choices=["batch", "stripes16k", "mono16k"], default="batch")
+    ap.add_argument("--side", type=int, default=16384, help="side of the square image of the 16k modes")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--content", choices=["natural", "noise"], default="natural")
@@ -110,24 +117,44 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
+    elif args.mode != "batch":
+        # the 16k modes run the exchange code with one rank too: a group of one
+        import socket
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        kw = {"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}
+        dist.init_process_group(backend=backend, init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, **kw)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pkg = importlib.import_module("jpeg-encoder_amd")
 
     if args.persistence is not None:
         pkg.synth.PERSISTENCE = args.persistence
-    w, h, nf = args.width, args.height, args.frames
+    if args.mode != "batch":
+        rc = bench_16k(args, pkg, torch, dist, dev, world, rank, backend)
+        dist.barrier()
+        dist.destroy_process_group()
+        return rc
+    w, h = args.width, args.height
+    if args.scaling == "strong":
+        first, last = pkg.distributed.shard_range(args.total_frames, rank, world)
+        nf = last - first
+    else:
+        nf, first = args.frames, rank * args.frames
+    total_frames = args.total_frames if args.scaling == "strong" else world * nf
     px_per_frame = w * h
-    # this rank's shard: frames [rank*nf, (rank+1)*nf) of the global batch, seeds 1000 + global index
+    # this rank's shard: frames [first, first + nf) of the global batch, seeds 1000 + global index
     frames = torch.empty((nf, h, w, 3), dtype=torch.uint8, device=dev)
     gen_chunk = 16
     for s in range(0, nf, gen_chunk):
         e = min(nf, s + gen_chunk)
         if args.content == "natural":
-            frames[s:e] = pkg.synth.natural_like_torch(e - s, h, w, 1000 + rank * nf + s, dev)
+            frames[s:e] = pkg.synth.natural_like_torch(e - s, h, w, 1000 + first + s, dev)
         else:
             g = torch.Generator(device=dev)
-            g.manual_seed(1000 + rank * nf + s)
+            g.manual_seed(1000 + first + s)
             frames[s:e] = torch.randint(0, 256, (e - s, h, w, 3), generator=g, device=dev, dtype=torch.uint8)
     cap_words = (px_per_frame * (6 if args.content == "noise" else 3)) // 4  # 3 (6) bytes per pixel of room
     words = torch.zeros((nf, cap_words), dtype=torch.int32, device=dev)
@@ -139,6 +166,7 @@ def main():
 
     if args.ws_mb:
         enc.set_workspace_limit(args.ws_mb << 20)
+    enc.reserve(nf, w, h)  # the steps below only enqueue work
 
     def step():
         enc.encode_batch_device(frames.data_ptr(), nf, w, h, w * 3, h * w * 3, words.data_ptr(), cap_words,
@@ -169,65 +197,193 @@ def main():
     res = results.cpu().numpy().view(pkg.RESULT_DTYPE).reshape(nf)
     ok = bool((res["status"] == 0).all())
     stuffed = int(res["total_bytes_stuffed"].sum())
+    unstuffed = int(res["total_bits_unstuffed"].sum()) // 8
     out_bytes_per_px = stuffed / float(nf * px_per_frame)
-    total_px = float(world) * nf * px_per_frame * args.steps
+    total_px = float(total_frames) * px_per_frame * args.steps
     value = total_px / elapsed / 1e6
+    if world > 1:  # a failed image on any rank fails the run
+        flag = torch.tensor([0 if ok else 1], dtype=torch.int64, device=dev)
+        dist.all_reduce(flag)
+        ok = int(flag.item()) == 0
 
+    content = (("natural-like" if args.persistence is None else "natural-like (persistence %.2f)" % args.persistence)
+               if args.content == "natural" else "uniform-noise")
+    tables = "RTL default (all-ones)" if args.quant == 1 else "all-%d" % args.quant
+    if args.scaling == "strong":
+        workload = ("%d x %dx%d RGB frames in all, %s content, %s quant tables, sharded by image over %d GPU(s): "
+                    "%d frames on this GPU" % (total_frames, w, h, content, tables, world, nf))
+    else:
+        workload = ("%d x %dx%d RGB frames per GPU, %s content, %s quant tables; "
+                    "8 GPUs = the 8192-frame 1080p configuration, sharded by image" % (nf, w, h, content, tables))
     line = {
         "metric": "encoded Mpixel/s (1080p RGB batch)", "value": round(value, 1), "unit": "Mpixel/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-        "config": {"workload": "%d x %dx%d RGB frames per GPU, %s content, %s quant tables; "
-                               "8 GPUs = the 8192-frame 1080p configuration, sharded by image"
-                               % (nf, w, h, ("natural-like" if args.persistence is None else
-                                             "natural-like (persistence %.2f)" % args.persistence)
-                                  if args.content == "natural" else "uniform-noise",
-                                  "RTL default (all-ones)" if args.quant == 1 else "all-%d" % args.quant),
-                   "frames_per_gpu": nf, "width": w, "height": h, "sharding": "independent images, no collective"},
+        "config": {"workload": workload, "frames_per_gpu": nf, "total_frames": total_frames, "width": w, "height": h,
+                   "sharding": "independent images, no collective"},
         "all_images_ok": ok, "out_bytes_per_pixel": round(out_bytes_per_px, 4),
     }
+    failed = not ok
     if rank == 0:
-        # roofline of the dominant kernel, live HIP-event durations of this run
-        alg_bytes_step = 3.0 * nf * px_per_frame + stuffed  # RGB read once + stuffed stream written once
+        # Rooflines from the live HIP-event durations of this run (events recorded by the library on its stream).
+        rgb_bytes = 3.0 * nf * px_per_frame
+        pipe_bytes = rgb_bytes + stuffed   # the path's algorithmic traffic: RGB read once + stuffed stream written once
+        enc_bytes = rgb_bytes + unstuffed  # what the dominant kernel itself moves: RGB in, unstuffed chunk streams out
         if not args.no_profile and ktimes["k_encode_chunks"][0] > 0:
             n_launch, ms_sum = ktimes["k_encode_chunks"]
             launches_per_step = n_launch / args.steps
             avg_ms = ms_sum / n_launch
-            achieved = alg_bytes_step / launches_per_step / (avg_ms * 1e-3) / 1e9
-            traffic = None
+            per_launch = enc_bytes / launches_per_step
+            achieved = per_launch / (avg_ms * 1e-3) / 1e9
+            all_ms = sum(v[1] for v in ktimes.values()) / args.steps
+            pipe_achieved = pipe_bytes / (all_ms * 1e-3) / 1e9
+            line["roofline"] = {
+                "bound": "hbm", "kernel": "k_encode_chunks", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": round(per_launch),
+                "algorithmic_bytes": "RGB bytes in + unstuffed chunk-stream bytes out of the frames of one launch",
+                "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
+                "pipeline": {"kernel": "all four kernels of a step", "achieved": round(pipe_achieved, 1),
+                             "frac": round(pipe_achieved / HBM_PEAK_GBPS, 4),
+                             "algorithmic_bytes_per_step": round(pipe_bytes),
+                             "algorithmic_bytes": "RGB bytes in + stuffed stream bytes out",
+                             "kernel_ms_per_step": round(all_ms, 4)},
+            }
             tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            valu_busy = None
-            if os.path.exists(tfile):
+            if os.path.exists(tfile):  # counters are not collected in this run: figures of the stored counter passes
                 try:
                     pmc = json.load(open(tfile))
                     per_frame = pmc.get("k_encode_chunks_hbm_bytes_per_frame")
-                    traffic = round(per_frame * nf / launches_per_step) if per_frame else None
-                    valu_busy = pmc.get("valu", {}).get("k_encode_chunks_valu_busy")
+                    valu = pmc.get("valu", {})
+                    ipw = valu.get("valu_instructions_per_wave")
+                    line["roofline"]["from_stored_profile"] = {
+                        "source": "profiles/pmc_traffic.json (%s)" % pmc.get("build", "rocprofv3 --pmc passes"),
+                        "traffic": round(per_frame * nf / launches_per_step) if per_frame else None,
+                        "valu_insts_per_wave": ipw,
+                        "lane_ops_per_pixel": round(ipw * 64 / 4096.0, 1) if ipw else None,
+                        "valu_busy": valu.get("k_encode_chunks_valu_busy"),
+                        "note": "the kernel is VALU-issue-bound; HBM is not its limit"}
                 except Exception:
-                    traffic = None
-            line["roofline"] = {"bound": "hbm", "kernel": "k_encode_chunks", "achieved": round(achieved, 1),
-                                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                                "traffic": traffic,
-                                "algorithmic_bytes_per_launch": round(alg_bytes_step / launches_per_step),
-                                "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step}
-            if valu_busy is not None:  # counter pass kept under profiles/: the kernel is issue-bound, not HBM-bound
-                line["roofline"]["valu_busy_from_profile"] = valu_busy
-            all_ms = sum(v[1] for v in ktimes.values()) / args.steps
+                    pass
             line["kernel_ms_per_step"] = {k: round(v[1] / args.steps, 4) for k, v in ktimes.items()}
-            line["pipeline_hbm_frac"] = round(alg_bytes_step / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
         if not args.no_cpu:
             n_cpu = min(args.cpu_frames, nf)
             frames_np = frames[:n_cpu].cpu().numpy()
             k_max = int((res["n_full_words"][:n_cpu] + 1).max())
             gw = words[:n_cpu, :min(cap_words, k_max)].cpu().numpy().view(np.uint32)
             line["cpu_baseline"] = cpu_baseline(list(frames_np), gw, res[:n_cpu], args.cpu_threads, qtabs)
+            failed = failed or line["cpu_baseline"]["mismatching_frames"] != 0
+        if failed:
+            line["error"] = "an image did not fit its output buffer or differs from the oracle: value is not valid"
         print(json.dumps(line))
     enc.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 1 if failed else 0
+
+
+def bench_16k(args, pkg, torch, dist, dev, world, rank, backend):
+    """The single huge image: `--mode stripes16k` codes it as 8 restart-interval stripes (stripe s on rank
+    s % world) and gathers table + payloads on rank 0; `--mode mono16k` codes one band per rank and merges the
+    bands into the one stream jpeg_top gives for the whole image.  A step is the whole job: coding plus the
+    exchange.  Stripe s is natural-like content of seed 7 + s, generated where it is needed."""
+    import numpy as np
+    n, stripes = args.side, 8
+    rows = n // stripes
+    if n % (8 * stripes) or stripes % world:
+        raise SystemExit("--side must be a multiple of 64 and the rank count must divide 8")
+    xdev = dev if backend == "nccl" else torch.device("cpu")  # gloo rehearsal: the exchange goes through host memory
+    enc = pkg.JpegTop(device=dev.index, stream=torch.cuda.current_stream().cuda_stream)
+
+    def stripe_pixels(s):
+        return pkg.synth.natural_like_torch(1, rows, n, 7 + s, dev)[0]
+
+    if args.mode == "stripes16k":
+        mine = pkg.distributed.stripes_of_rank(stripes, rank, world)
+        local_img = torch.cat([stripe_pixels(s) for s in mine])  # this rank's stripes, one under the other
+        coder = pkg.distributed.hip_stripe_coder(enc, local_img, len(mine))
+
+        def step():
+            local = {}
+            for k, s in enumerate(mine):
+                wds, res = coder(k)
+                local[s] = (wds.to(xdev), res)
+            return pkg.distributed.gather_stripes(local, stripes, device=xdev)
+    else:
+        per = stripes // world
+        parts = [stripe_pixels(s) for s in range(rank * per, (rank + 1) * per)]
+        if rank:
+            parts.insert(0, stripe_pixels(rank * per - 1)[-8:])  # the 8 pixel rows above the band: DC predictors
+        local_img = torch.cat(parts)
+        lo = 8 if rank else 0
+
+        class Band(pkg.distributed.HipBand):
+            def write(self, ff_offset, is_last):
+                fw, wds, res = super().write(ff_offset, is_last)
+                return fw, wds.to(xdev), res
+
+        def step():
+            return pkg.distributed.encode_monolithic(Band(enc, local_img, lo, lo + per * rows), device=xdev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    rc = 0
+    if rank == 0:
+        if args.mode == "stripes16k":
+            table, payload = out
+            # the container: offsets are the running sum of the stripes' word counts, payload holds them all
+            sizes = table[:, 6]
+            good = bool((table[:, 0] == np.concatenate([[0], np.cumsum(sizes)[:-1]])).all()
+                        and int(sizes.sum()) == payload.numel()
+                        and (table[:, 1] + (table[:, 2] != 0) == sizes).all())
+            out_bytes = int(table[:, 5].sum())
+            extra = {"stripes": stripes, "container_consistent": good, "payload_words": int(payload.numel())}
+        else:
+            wds, res = out
+            good = int(res["status"]) == 0 and int(res["n_full_words"]) + (1 if res["tail_bits"] else 0) <= wds.numel()
+            out_bytes = int(res["total_bytes_stuffed"])
+            extra = {"bands": world, "stream_words": int(res["n_full_words"])}
+        if not args.no_cpu:  # one stripe against the oracle (2 s of CPU): stripe 0 is also band 0's first rows
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O
+            t0 = time.perf_counter()
+            want, r = O.encode(local_img[:rows].cpu().numpy()) if args.mode == "stripes16k" else (None, None)
+            if want is not None:
+                got = payload[:len(want)].cpu().numpy().view(np.uint32)
+                good = good and np.array_equal(got, want) and int(table[0, 3]) == r.tail_word
+                extra["cpu_baseline"] = {"value": round(rows * n / (time.perf_counter() - t0) / 1e6, 2), "unit": "Mpixel/s",
+                                         "cores": 1, "kind": "port", "sample": "stripe 0 (%d x %d), compared word for word" % (n, rows)}
+        rc = 0 if good else 1
+        line = {"metric": "encoded Mpixel/s (one %dx%d image, %s)" % (n, n, args.mode), "value": round(n * n * args.steps / elapsed / 1e6, 1),
+                "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+                "config": {"workload": "one %dx%d natural-like RGB image, %s, exchange over %s" % (
+                    n, n, "8 restart-interval stripes gathered on rank 0" if args.mode == "stripes16k"
+                    else "one band per rank merged into jpeg_top's single stream", backend)},
+                "out_bytes_per_pixel": round(out_bytes / float(n * n), 4), "result_ok": bool(good)}
+        line.update(extra)
+        print(json.dumps(line))
+    enc.close()
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
