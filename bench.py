@@ -44,6 +44,8 @@ def parse_args():
                     help="octave amplitude ratio of the natural-like generator (default 0.7; larger = more detail)")
     ap.add_argument("--quant", type=int, default=1, help="every quantiser table entry (1: the RTL default)")
     ap.add_argument("--ws-mb", type=int, default=0, help="workspace limit in MiB (0: library default)")
+    ap.add_argument("--regions", choices=["auto", "small", "large"], default="auto",
+                    help="LDS staging regions of the encode kernel (jpegenc_set_region_mode)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     return ap.parse_args()
@@ -166,6 +168,7 @@ def main():
 
     if args.ws_mb:
         enc.set_workspace_limit(args.ws_mb << 20)
+    enc.set_region_mode({"auto": enc.REGIONS_AUTO, "small": enc.REGIONS_SMALL, "large": enc.REGIONS_LARGE}[args.regions])
     enc.reserve(nf, w, h)  # the steps below only enqueue work
 
     def step():

@@ -206,6 +206,18 @@ const char* jpegenc_kernel_name(int index);
  * sub-batches are halved until they fit; JPEGENC_E_NOMEM when not even one image does. */
 int jpegenc_set_workspace_limit(jpegenc_ctx* ctx, size_t bytes);
 
+/* How the encode kernel sizes the per-block staging regions in LDS.  No counterpart in jpeg_top and no
+ * effect on the output: only on speed.  Small regions (1248 bits per block of Y, Cb and Cr together) let
+ * twelve wavefronts share a compute unit and are right for photographic content up to about 2 bytes per
+ * pixel; a group of 64 blocks that holds a longer block is coded twice.  Large regions (2016 bits) never
+ * need that below about 3.9 bytes per pixel and cost 9 % where small ones suffice.  AUTO (default): the
+ * kernel counts the groups with a too-long block in every launch and the context switches when, in the
+ * launches before, more than 12 % (back: fewer than 6 %) of the groups had one. */
+#define JPEGENC_REGIONS_AUTO 0
+#define JPEGENC_REGIONS_SMALL 1
+#define JPEGENC_REGIONS_LARGE 2
+int jpegenc_set_region_mode(jpegenc_ctx* ctx, int mode);
+
 /* Grows the workspace now to what jpegenc_encode_batch(n_images, w, h) will need (under the limit
  * above), so that later device-pointer calls of at most that size only enqueue work: no allocation, no
  * device synchronisation.  The workspace never shrinks before jpegenc_destroy.  No counterpart in

@@ -106,6 +106,14 @@ struct jpegenc_ctx {
     hipEvent_t ws_event = nullptr;
     bool ws_pending = false;
 
+    // Choice of the encode kernel's LDS region size (jpegenc_set_region_mode): the kernel counts, per launch,
+    // the chunks that hold an MCU too long for a small region; the counts reach `stats_host` (pinned) by an
+    // asynchronous copy behind the launch and steer the launches after it.
+    int region_mode = JPEGENC_REGIONS_AUTO;
+    bool large_regions = false;
+    DevBuf<uint32_t> stats;
+    uint32_t* stats_host = nullptr;
+
     // jpegenc_encode_batch_noalloc: this device's copy of the library's static workspace
     uint8_t* static_ws = nullptr;
 
@@ -282,6 +290,40 @@ int workspace_used(jpegenc_ctx* ctx) {
     return JPEGENC_OK;
 }
 
+// Region size for the next launch of the encode kernel, and its statistics buffer (zeroed on the stream).  Only
+// the common kernel variant (8-byte-aligned rows, all-ones tables) exists with large regions.
+int choose_regions(jpegenc_ctx* ctx, EncodeParams* ep, int align) {
+    ep->stats = nullptr;
+    ep->large_regions = 0;
+    if (ctx->quant || align < 8) return JPEGENC_OK;
+    if (ctx->region_mode == JPEGENC_REGIONS_AUTO) {
+        // whatever the last completed copy left in the pinned words: a heuristic, any value is safe
+        const volatile uint32_t* h = ctx->stats_host;
+        uint64_t over = 0;
+        for (int i = 0; i < 16; ++i) over += h[16 * i];
+        const uint64_t total = h[16 * 16];
+        if (total >= 256 && over <= total) {
+            // A chunk with such an MCU costs a second pass with small regions; large regions cost every
+            // chunk about 9 % (two waves per SIMD instead of three).
+            if (!ctx->large_regions && over * 100 > total * 12) ctx->large_regions = true;
+            if (ctx->large_regions && over * 100 < total * 6) ctx->large_regions = false;
+        }
+    } else {
+        ctx->large_regions = ctx->region_mode == JPEGENC_REGIONS_LARGE;
+    }
+    ep->large_regions = ctx->large_regions ? 1u : 0u;
+    ep->stats = ctx->stats.p;
+    HIPCHK(ctx, hipMemsetAsync(ctx->stats.p, 0, kEncodeStatsWords * 4, ctx->stream));
+    return JPEGENC_OK;
+}
+
+// Behind the encode launch: its statistics on their way to the host (no synchronisation; read by later calls).
+int collect_stats(jpegenc_ctx* ctx, const EncodeParams& ep) {
+    if (!ep.stats) return JPEGENC_OK;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->stats_host, ctx->stats.p, kEncodeStatsWords * 4, hipMemcpyDeviceToHost, ctx->stream));
+    return JPEGENC_OK;
+}
+
 // The launches for n images (one launch group) with the workspace `ws`.  All pointers are device memory.
 // `timed`: bracket the kernels with events when profiling is on (creates events).
 int run_group(jpegenc_ctx* ctx, const Workspace& ws, bool timed, const Plan& pl, const uint8_t* rgb, uint32_t n,
@@ -307,10 +349,14 @@ int run_group(jpegenc_ctx* ctx, const Workspace& ws, bool timed, const Plan& pl,
     ep.chunk_bits = ws.chunk_bits;
     ep.htab = ctx->htab.p;
     ep.qmul = ctx->quant ? ctx->qmul.p : nullptr;
+    int rc_regions = choose_regions(ctx, &ep, align);
+    if (rc_regions != JPEGENC_OK) return rc_regions;
     {
         ProfScope ps(ctx, K_ENCODE);
         HIPCHK(ctx, launch_encode(ep, n, align, ctx->stream));
     }
+    rc_regions = collect_stats(ctx, ep);
+    if (rc_regions != JPEGENC_OK) return rc_regions;
     // a frame or a few: the stuffing kernels work out the prefixes themselves, two launches fewer
     const bool inline_scan = uint64_t(n) * cpi <= kInlineScanChunks && cpi <= kInlineScanMaxCpi;
     ScanParams sp;
@@ -509,6 +555,9 @@ int jpegenc_create(jpegenc_ctx** out, const jpegenc_config* cfg) {
     ctx->quant = !all_ones;
     e = ctx->htab.reserve(kHtabEntries);
     if (e == hipSuccess) e = ctx->qmul.reserve(3 * 64);
+    if (e == hipSuccess) e = ctx->stats.reserve(kEncodeStatsWords);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&ctx->stats_host), kEncodeStatsWords * 4, hipHostMallocDefault);
+    if (e == hipSuccess) std::memset(ctx->stats_host, 0, kEncodeStatsWords * 4);
     if (e == hipSuccess) e = hipMemcpy(ctx->htab.p, htab, sizeof htab, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ctx->qmul.p, qmul, sizeof qmul, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -530,6 +579,8 @@ int jpegenc_destroy(jpegenc_ctx* ctx) {
     }
     ctx->htab.release();
     ctx->qmul.release();
+    ctx->stats.release();
+    if (ctx->stats_host) (void)hipHostFree(ctx->stats_host);
     ctx->slots.release();
     ctx->chunk_bits.release();
     ctx->chunk_ff.release();
@@ -739,7 +790,12 @@ int jpegenc_segment_encode(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int rows
     ep.htab = ctx->htab.p;
     ep.qmul = ctx->quant ? ctx->qmul.p : nullptr;
     // the block row above must be as aligned as the segment's own rows: the stride takes care of that
-    HIPCHK(ctx, launch_encode(ep, 1, pointer_align(d_rgb, d_stride, 0, 1, rows), ctx->stream));
+    const int seg_align = pointer_align(d_rgb, d_stride, 0, 1, rows);
+    int rc_regions = choose_regions(ctx, &ep, seg_align);
+    if (rc_regions != JPEGENC_OK) return rc_regions;
+    HIPCHK(ctx, launch_encode(ep, 1, seg_align, ctx->stream));
+    rc_regions = collect_stats(ctx, ep);
+    if (rc_regions != JPEGENC_OK) return rc_regions;
     ScanParams sp;
     sp.counts = ctx->chunk_bits.p;
     sp.prefix = ctx->bit_off.p;
@@ -952,6 +1008,12 @@ int jpegenc_kernel_times(jpegenc_ctx* ctx, uint64_t launches[JPEGENC_N_KERNELS],
 
 const char* jpegenc_kernel_name(int index) {
     return (index >= 0 && index < JPEGENC_N_KERNELS) ? kKernelNames[index] : "";
+}
+
+int jpegenc_set_region_mode(jpegenc_ctx* ctx, int mode) {
+    if (!ctx || mode < JPEGENC_REGIONS_AUTO || mode > JPEGENC_REGIONS_LARGE) return JPEGENC_E_BAD_ARG;
+    ctx->region_mode = mode;
+    return JPEGENC_OK;
 }
 
 int jpegenc_set_workspace_limit(jpegenc_ctx* ctx, size_t bytes) {

@@ -498,22 +498,36 @@ __device__ __forceinline__ int halo_dc(int sample, bool luma, int qm0, bool do_q
 // ------------------------------------------------------------------------------------------------
 // k_encode_chunks
 // ------------------------------------------------------------------------------------------------
-// LDS budget: 64 regions of 41 words, sized so that twelve workgroups (three waves per SIMD) fit the
-// 160 KB of a CU.  Tier 1 gives every lane one region (39 usable words = 1248 bits per MCU, 2.4 bytes per
-// pixel: enough for photographic content); if any lane overflows, the chunk is redone with 2 groups of
-// 32 lanes (two regions each, 80 words), then with 4 groups of 16 lanes (four regions, 162 words -- more
-// than the 156-word worst case of an MCU).  Odd region strides keep lanes on different LDS banks.
-constexpr int kRegionWords = 41;
-constexpr int kOwnWords = kRegionWords - 1;  // first tier: 39 usable words and one zero word behind them
-static_assert(kOwnWords % 8 == 0, "the in-register concatenation works in blocks of 8 words");
-// The regions plus room for the unguarded tier-1 overrun of the last lane (156 words from its base).
-constexpr int kPrivWords = 64 * kRegionWords + 120;
-static_assert(63 * kRegionWords + kMaxMcuWords <= kPrivWords, "tier-1 overrun of the last lane");
-static_assert(4 * kRegionWords - 2 >= kMaxMcuWords, "tier 3 must hold the worst-case MCU");
+// LDS budget: 64 regions of REGION words plus the Huffman table.  REGION = 41 lets twelve workgroups (three
+// waves per SIMD) share the 160 KB of a CU: the first pass gives every lane one region (39 usable words = 1248
+// bits per MCU, 2.4 bytes per pixel: enough for photographic content); if any lane overflows, the chunk is
+// redone with regions cut to the lengths the first pass has counted.  REGION = 65 (63 usable words = 2016
+// bits, 3.9 bytes per pixel) is for content that would overflow often: eight workgroups per CU, 9 % slower
+// where 41 words suffice and up to twice as fast where they do not.  The host picks one per launch from the
+// overflow counts of its previous launches (see EncodeParams::stats).  Odd region strides keep lanes on
+// different LDS banks.
+[[maybe_unused]] constexpr int kRegionSmall = 41, kRegionLarge = 65;
+constexpr uint32_t kSmallRegionBits = (kRegionSmall - 2) * 32;  // what a lane may emit in a small region
 
+// End of the range of lanes [lo, hi) that one exact-fit pass can hold: `need_incl` is the inclusive prefix
+// sum of the lanes' region sizes, `before_lo` the sum over the lanes before `lo`.
+__device__ __forceinline__ uint32_t fit_range_end(uint32_t need_incl, uint32_t lo, uint32_t before_lo, uint32_t kFitWords) {
+    // the sums grow with the lane, so the lanes that fit are lo, lo + 1, ... up to the first that does not
+    // (for the lanes before lo the difference wraps to a huge number; they are shifted out)
+    const uint64_t fits = __ballot((int)(need_incl - before_lo <= kFitWords)) >> lo;
+    return lo + (uint32_t)__popcll(fits);
+}
 
-template <int ALIGN, bool QUANT, bool WRAP>
-__global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
+template <int ALIGN, bool QUANT, bool WRAP, int REGION>
+__global__ __launch_bounds__(64, REGION > kRegionSmall ? 2 : 3) void k_encode_chunks(EncodeParams p) {
+    constexpr int kRegionWords = REGION;
+    constexpr int kOwnWords = kRegionWords - 1;  // first pass: REGION - 2 usable words and one zero word behind them
+    static_assert(kOwnWords % 8 == 0, "the in-register concatenation works in blocks of 8 words");
+    // The regions plus room for the unguarded overrun of the last lane in the first pass (156 words from its base).
+    constexpr int kPrivWords = 64 * kRegionWords + 120;
+    static_assert(63 * kRegionWords + kMaxMcuWords <= kPrivWords, "first-pass overrun of the last lane");
+    constexpr uint32_t kFitWords = 64 * kRegionWords;  // what the exact regions of one pass may add up to
+    static_assert(kFitWords >= 16 * (kMaxMcuWords + 2), "a pass holds at least 16 worst-case MCUs");
     __shared__ __attribute__((aligned(16))) uint32_t priv[kPrivWords];
     __shared__ uint32_t htab[kHtabEntries];  // code << size
     __shared__ uint8_t hlen[kHtabEntries];   // code length + size
@@ -591,23 +605,23 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
     uint32_t carry = 0;        // partial last word of the slot (left-aligned), when chunk_total % 32 != 0
     uint32_t tail8 = 0;        // last 8 bits of the stream so far (uniform)
 
-    // Tier loop: n_groups = 1, 2 or 4 groups of 64/n_groups lanes coding at once (see kRegionWords).
-    // Between the first tier and the group tiers: when a lane overflowed its region but the chunk as a whole
-    // fits, the chunk is redone once with every lane given exactly the words it needs (`fit`; the lengths
-    // are known from the first pass, which counts every lane's bits even when it cannot store them).
-    int n_groups = 1;
+    // Pass loop.  The first pass codes all 64 lanes at once, every lane into its own region (see kRegionWords).
+    // It counts every lane's bits even when a lane cannot store them, so if any lane overflowed its region
+    // the lengths of all 64 strings are known, and the chunk is redone with every lane given exactly the
+    // words it needs (`fit`): in one more pass when the whole chunk fits the LDS, else in as few passes over
+    // consecutive lane ranges [lo, hi) as the LDS allows (uniform noise: two ranges; the worst case of 156
+    // words per lane: four).  Lanes outside the range of a pass compute along and store nothing.
     bool fit = false;
-    uint32_t fit_base = 0, fit_cap = 0;
-    for (int g = 0; g < n_groups; ++g) {
-        const int lg = n_groups >> 1;  // log2 of 1, 2, 4
-        const int lanes_per_group = 64 >> lg;
-        const uint32_t stride = (uint32_t)kRegionWords << lg;
-        const uint32_t cap = fit ? fit_cap : stride - 2u;
-        const bool active = valid && (lane >> (6 - lg)) == g;
-        const uint32_t base = fit ? fit_base : (uint32_t)(lane & (lanes_per_group - 1)) * stride;
+    uint32_t lo = 0, hi = 64;             // lanes coded by this pass (uniform)
+    uint32_t need = 0, need_before = 0;   // fit: words of this lane's region, and of all lanes before it
+    for (;;) {
+        const bool active = valid && (uint32_t)lane >= lo && (uint32_t)lane < hi;
+        const uint32_t cap = fit ? need - 2u : (uint32_t)kRegionWords - 2u;
         // region: word 0 takes the stores of the bit writer that are not meant to land, words [1, 1+cap)
-        // the string, one more word the zero behind a full string; lanes of other groups count their
-        // bits but store nothing
+        // the string, one more word the zero behind a full string; the lanes outside the range send all their
+        // stores to word 0 of the first region
+        const uint32_t base = !fit ? (uint32_t)lane * kRegionWords
+                                   : (active ? need_before - readlane_u32(need_before, (int)lo) : 0u);
         BitWriter bw;
         bw.win = 0;
         bw.T = base * 32u;
@@ -619,7 +633,8 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
             int x[64];
             // The MCU's 192 bytes are fetched again for every component (mostly from L2): holding them in 48
             // registers across the components spills at the register budget of three waves per SIMD,
-            // and the scratch traffic then exceeds the saved fetches (measured).
+            // and the scratch traffic then exceeds the saved fetches; with large regions and two waves per SIMD
+            // they fit (255 registers), and the kernel is 3 to 12 % slower for it (both measured).
             uint32_t raw[48];
             if constexpr (ALIGN == 8) {
                 if (comp == 2)
@@ -663,47 +678,46 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
             const int h = (comp == 0) ? halo[0] : (comp == 1) ? halo[1] : halo[2];
             // DC of the lane before; lane 0 has no source and keeps h (wave_shr:1)
             const int pred = __builtin_amdgcn_update_dpp(h, x[0], 0x138, 0xF, 0xF, false);
-            if (n_groups == 1 && !fit)
+            if (!fit)
                 encode_block<false, QUANT>(x, pred, comp == 1 && cb_quirk, htab, hlen, priv, bw);
             else
                 encode_block<true, QUANT>(x, pred, comp == 1 && cb_quirk, htab, hlen, priv, bw);
         }
-        // Every lane counts its bits whether or not it may store them, so the first pass already knows
-        // which tier the chunk needs.
         const uint32_t Lall = valid ? (bw.T - base * 32u) : 0u;
         // flush the residual bits, left-aligned and zero-filled
         if (active && Lall <= cap * 32u) {
             if ((bw.T & 31u) != 0) priv[(bw.T >> 5) + 1u] = (uint32_t)bw.win << ((0u - bw.T) & 31u);
             priv[((bw.T + 31u) >> 5) + 1u] = 0u;  // one zero word behind the string
         }
-        if (n_groups == 1 && !fit && __any((int)(Lall > cap * 32u))) {
-            // words per lane: the unread word 0, the string, the zero word behind it
-            const uint32_t need = ((Lall + 31u) >> 5) + 2u;
-            uint32_t need_total;
-            const uint32_t need_off = wave_excl_scan_u32(need, &need_total);
-            if (need_total <= 64u * kRegionWords) {
-                fit = true;
-                fit_base = need_off;
-                fit_cap = need - 2u;
-            } else {
-                n_groups = __any((int)(Lall > (2u * kRegionWords - 2u) * 32u)) ? 4 : 2;
-            }
-            g = -1;  // restart the chunk on that tier
-            __syncthreads();
-            continue;
+        if (!fit && p.stats) {
+            // for the host's choice of REGION: chunks with an MCU beyond the small region, spread over 16
+            // counters on lines of their own, and the launch's chunk count beside them
+            if (__any((int)(Lall > kSmallRegionBits)) && lane == 0)
+                __hip_atomic_fetch_add(&p.stats[(gid & 15u) * 16u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (gid == 0 && lane == 0) p.stats[16 * 16] = p.n_images * p.cpi;
         }
-        const uint32_t L = active ? Lall : 0u;  // bits of this lane's string in this group
+        if (!fit && __any((int)(Lall > cap * 32u))) {
+            // words per lane: the unread word 0, the string, the zero word behind it
+            need = ((Lall + 31u) >> 5) + 2u;
+            uint32_t need_total;
+            need_before = wave_excl_scan_u32(need, &need_total);
+            fit = true;
+            lo = 0;
+            hi = fit_range_end(need_before + need, 0u, 0u, kFitWords);
+            __syncthreads();
+            continue;  // restart the chunk with exact regions
+        }
+        const uint32_t L = active ? Lall : 0u;  // bits of this lane's string in this pass
         __syncthreads();  // strings visible to all lanes
 
-        // ---- concatenate the group's strings in place, in lane order, at LDS word 0 -------------
-        // One source string per step, all 64 lanes moving one word each.  Destination word d0+t is
-        // (src[t-1]:src[t]) >> s; src[t-1] comes from the neighbouring lane, the bits a string shares
-        // with its predecessor's last word travel in `tailw` (wave-uniform).  In place is safe because a
-        // string never moves to a higher address and all reads of a step precede its writes.
+        // ---- concatenate the strings of this pass in place, in lane order, at LDS word 0 ----------
+        // Destination word d0+t is (src[t-1]:src[t]) >> s; the bits a string shares with its predecessor's
+        // last word travel in `tailw` (wave-uniform).  In place is safe because a string never moves to a
+        // higher address and all reads of a step precede its writes.
         uint32_t gtotal;
         const uint32_t off = wave_excl_scan_u32(L, &gtotal);
-        if (n_groups == 1 && !fit) {
-            // First tier, every lane at once: each lane takes its whole string (at most kOwnWords words,
+        if (!fit) {
+            // First pass, every lane at once: each lane takes its whole string (at most kOwnWords words,
             // the last one zero) into registers, the destination range is cleared, and every lane ORs
             // its words, shifted to its bit offset, into place.  Words shared by neighbouring strings
             // get their parts from several lanes, hence the OR.  In place is safe because all reads
@@ -737,23 +751,21 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
             }
             wave_sync();
         }
-        const int first = g * lanes_per_group;
         uint32_t tailw = 0;
-        for (int m = 0; (n_groups != 1 || fit) && m < lanes_per_group; ++m) {
-            const int M = first + m;
-            const uint32_t LM = readlane_u32(L, M);
+        for (uint32_t M = lo; fit && M < hi; ++M) {  // one source string per step, all 64 lanes moving one word each
+            const uint32_t LM = readlane_u32(L, (int)M);
             if (LM == 0) continue;  // uniform
-            const uint32_t oM = readlane_u32(off, M);
-            const uint32_t bM = readlane_u32(base, M) + 1u;
+            const uint32_t oM = readlane_u32(off, (int)M);
+            const uint32_t bM = readlane_u32(base, (int)M) + 1u;
             const uint32_t s = oM & 31u, d0 = oM >> 5;
             const uint32_t nw = (LM + 31u) >> 5;      // source words
             const uint32_t nd = (s + LM + 31u) >> 5;  // destination words touched
             if (nd <= 64u) {
                 const uint32_t t = lane;
-                const uint32_t lo = (t < nw) ? priv[bM + t] : 0u;
-                uint32_t hi = __shfl_up(lo, 1);
-                if (t == 0) hi = 0u;
-                uint32_t w = __builtin_amdgcn_alignbit(hi, lo, s);
+                const uint32_t wlo = (t < nw) ? priv[bM + t] : 0u;
+                uint32_t whi = __shfl_up(wlo, 1);
+                if (t == 0) whi = 0u;
+                uint32_t w = __builtin_amdgcn_alignbit(whi, wlo, s);
                 if (t == 0) w |= tailw;
                 __syncthreads();  // all reads of this step before its writes
                 if (t < nd) priv[d0 + t] = w;
@@ -762,9 +774,9 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
             } else {
                 for (uint32_t t0 = 0; t0 < nd; t0 += 64) {
                     const uint32_t t = t0 + lane;
-                    const uint32_t lo = (t < nw) ? priv[bM + t] : 0u;
-                    const uint32_t hi = (t >= 1 && t - 1 < nw) ? priv[bM + t - 1] : 0u;
-                    uint32_t w = __builtin_amdgcn_alignbit(hi, lo, s);
+                    const uint32_t wlo = (t < nw) ? priv[bM + t] : 0u;
+                    const uint32_t whi = (t >= 1 && t - 1 < nw) ? priv[bM + t - 1] : 0u;
+                    uint32_t w = __builtin_amdgcn_alignbit(whi, wlo, s);
                     if (t == 0) w |= tailw;
                     __syncthreads();
                     if (t < nd) priv[d0 + t] = w;
@@ -774,37 +786,37 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
             }
         }
 
-        // ---- append the group's stream to the slot at bit offset chunk_total ---------------------
+        // ---- append the stream of this pass to the slot at bit offset chunk_total -----------------
         if (gtotal != 0) {
             const uint32_t s = chunk_total & 31u, d0 = chunk_total >> 5;
             const uint32_t nw = (gtotal + 31u) >> 5;
             const uint32_t nd = (s + gtotal + 31u) >> 5;
-            // The chunk's only group (first and fit tiers) starts the slot: whole groups of four words go out
-            // as they are, four per lane and step; the general loop below is left with the last 0 to 3 words.
+            // The chunk's first pass starts the slot: whole groups of four words go out as they are, four per
+            // lane and step; the general loop below is left with the last 0 to 3 words.
             uint32_t t_first = lane;
-            if (!QUANT && n_groups == 1) {
+            if (!QUANT && chunk_total == 0) {
                 const uint32_t nq = nd >> 2;
                 for (uint32_t q = lane; q < nq; q += 64)
                     __builtin_nontemporal_store(reinterpret_cast<const u32x4*>(priv)[q], reinterpret_cast<u32x4*>(slot) + q);
                 t_first = 4u * nq + lane;
             }
             for (uint32_t t = t_first; t < nd; t += 64) {
-                const uint32_t lo = (t < nw) ? priv[t] : 0u;
-                const uint32_t hi = (t >= 1 && t - 1 < nw) ? priv[t - 1] : 0u;
-                uint32_t w = __builtin_amdgcn_alignbit(hi, lo, s);
+                const uint32_t wlo = (t < nw) ? priv[t] : 0u;
+                const uint32_t whi = (t >= 1 && t - 1 < nw) ? priv[t - 1] : 0u;
+                uint32_t w = __builtin_amdgcn_alignbit(whi, wlo, s);
                 if (t == 0) w |= carry;
                 __builtin_nontemporal_store(w, &slot[d0 + t]);  // streamed: keeps the pixels in L2 for the next component
             }
             const uint32_t nt = chunk_total + gtotal;
-            {   // the last 8 bits of the stream so far (a non-empty group has at least 18 bits)
+            {   // the last 8 bits of the stream so far (a non-empty pass has at least 18 bits)
                 const uint32_t l = gtotal - 8u, wi = l >> 5, sh = l & 31u;
                 tail8 = (sh ? ((priv[wi] << sh) | (priv[wi + 1] >> (32u - sh))) : priv[wi]) >> 24;
             }
-            if (nt & 31u) {  // keep the partial last word for the next group (uniform)
+            if (nt & 31u) {  // keep the partial last word for the next pass (uniform)
                 const uint32_t t = nd - 1;
-                const uint32_t lo = (t < nw) ? priv[t] : 0u;
-                const uint32_t hi = (t >= 1 && t - 1 < nw) ? priv[t - 1] : 0u;
-                uint32_t w = s ? ((hi << (32u - s)) | (lo >> s)) : lo;
+                const uint32_t wlo = (t < nw) ? priv[t] : 0u;
+                const uint32_t whi = (t >= 1 && t - 1 < nw) ? priv[t - 1] : 0u;
+                uint32_t w = s ? ((whi << (32u - s)) | (wlo >> s)) : wlo;
                 if (t == 0) w |= carry;
                 carry = w;
             } else {
@@ -812,7 +824,10 @@ __global__ __launch_bounds__(64, 3) void k_encode_chunks(EncodeParams p) {
             }
             chunk_total = nt;
         }
-        __syncthreads();  // LDS free for the next group
+        if (hi >= 64u) break;
+        __syncthreads();  // LDS free for the next range of lanes
+        lo = hi;
+        hi = fit_range_end(need_before + need, lo, readlane_u32(need_before, (int)lo), kFitWords);
     }
     // bit count (at most 64 * 4980 < 2^24) and, for the successor's first byte, the stream's last 8 bits
     if (lane == 0) p.chunk_bits[gid] = chunk_total | (tail8 << 24);
@@ -1250,20 +1265,20 @@ hipError_t static_workspace(void** ptr) {
 // This file is compiled twice.  The variants of k_encode_chunks with a quantiser are built in a translation
 // unit of their own (-DJPEGENC_TU_QUANT) with the scheduler's max-ILP strategy: there it removes their spills
 // (9 % faster), while the variants for the all-ones tables lose 5 % under it and keep the default strategy.
-template <int ALIGN, bool QUANT>
+template <int ALIGN, bool QUANT, int REGION>
 static hipError_t launch_encode_b(const EncodeParams& p, dim3 grid, hipStream_t s) {
     if (p.flags & 1u)
-        hipLaunchKernelGGL((k_encode_chunks<ALIGN, QUANT, true>), grid, dim3(64), 0, s, p);
+        hipLaunchKernelGGL((k_encode_chunks<ALIGN, QUANT, true, REGION>), grid, dim3(64), 0, s, p);
     else
-        hipLaunchKernelGGL((k_encode_chunks<ALIGN, QUANT, false>), grid, dim3(64), 0, s, p);
+        hipLaunchKernelGGL((k_encode_chunks<ALIGN, QUANT, false, REGION>), grid, dim3(64), 0, s, p);
     return hipGetLastError();
 }
 
 #ifdef JPEGENC_TU_QUANT
 hipError_t launch_encode_quant(const EncodeParams& p, dim3 grid, int align, hipStream_t s) {
-    if (align >= 8) return launch_encode_b<8, true>(p, grid, s);
-    if (align >= 4) return launch_encode_b<4, true>(p, grid, s);
-    return launch_encode_b<1, true>(p, grid, s);
+    if (align >= 8) return launch_encode_b<8, true, kRegionSmall>(p, grid, s);
+    if (align >= 4) return launch_encode_b<4, true, kRegionSmall>(p, grid, s);
+    return launch_encode_b<1, true, kRegionSmall>(p, grid, s);
 }
 #else
 hipError_t launch_encode_quant(const EncodeParams& p, dim3 grid, int align, hipStream_t s);
@@ -1279,9 +1294,10 @@ hipError_t launch_encode(const EncodeParams& p_in, uint32_t n_images, int align,
     if (nz > 65535u) return hipErrorInvalidValue;
     const dim3 grid(p.cpi, ny, nz);
     if (p.qmul) return launch_encode_quant(p, grid, align, s);
-    if (align >= 8) return launch_encode_b<8, false>(p, grid, s);
-    if (align >= 4) return launch_encode_b<4, false>(p, grid, s);
-    return launch_encode_b<1, false>(p, grid, s);
+    // large regions exist for the common variant only (8-byte-aligned rows, all-ones tables: quantised streams are short)
+    if (align >= 8) return p.large_regions ? launch_encode_b<8, false, kRegionLarge>(p, grid, s) : launch_encode_b<8, false, kRegionSmall>(p, grid, s);
+    if (align >= 4) return launch_encode_b<4, false, kRegionSmall>(p, grid, s);
+    return launch_encode_b<1, false, kRegionSmall>(p, grid, s);
 }
 
 hipError_t launch_scan(const ScanParams& p, uint32_t n_images, hipStream_t s) {

@@ -265,3 +265,53 @@ def test_segment_state_is_dropped_by_other_calls_and_one_chunk_last_band():
         finally:
             for b in bands:
                 b.close()
+
+
+def test_region_modes_give_the_same_stream():
+    """The encode kernel exists with small and with large LDS staging regions; the context picks one per launch
+    from the overflow counts of the launches before.  Whatever it picks, the words are the oracle's: easy,
+    detailed and noise content under both forced modes, and a run in automatic mode that starts on easy
+    content, meets detailed content (switches to large regions) and returns to easy content."""
+    pkg = load_pkg()
+    dev = torch.device("cuda:0")
+    h, w, n = 256, 1024, 6  # 6 x 64 chunks per call: enough for the automatic mode to act on
+    g = torch.Generator(device=dev)
+    g.manual_seed(31)
+    easy = pkg.synth.natural_like_torch(n, h, w, 40, dev)
+    keep = pkg.synth.PERSISTENCE
+    pkg.synth.PERSISTENCE = 3.0
+    try:
+        detailed = pkg.synth.natural_like_torch(n, h, w, 41, dev)
+    finally:
+        pkg.synth.PERSISTENCE = keep
+    noise = torch.randint(0, 256, (n, h, w, 3), generator=g, device=dev, dtype=torch.uint8)
+    cap = pkg.max_words(w, h)
+    want = {}
+
+    def run(e, name, frames):
+        d_words = torch.zeros((n, cap), dtype=torch.int32, device=dev)
+        d_res = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
+        e.encode_batch_device(frames.data_ptr(), n, w, h, w * 3, h * w * 3, d_words.data_ptr(), cap, d_res.data_ptr())
+        torch.cuda.synchronize()
+        res = d_res.cpu().numpy().view(pkg.RESULT_DTYPE).reshape(n)
+        assert (res["status"] == 0).all()
+        out = []
+        for i in range(n):
+            k = int(res[i]["n_full_words"]) + (1 if res[i]["tail_bits"] else 0)
+            out.append(d_words[i, :k].cpu().numpy().view(np.uint32))
+        if name not in want:  # the oracle's words, once per content
+            host = frames.cpu().numpy()
+            want[name] = [O.encode(host[i])[0] for i in range(n)]
+        for i in range(n):
+            assert np.array_equal(out[i], want[name][i]), (name, i)
+
+    contents = (("easy", easy), ("detailed", detailed), ("noise", noise))
+    for mode in (pkg.JpegTop.REGIONS_SMALL, pkg.JpegTop.REGIONS_LARGE):
+        with pkg.JpegTop(stream=torch.cuda.current_stream().cuda_stream) as e:
+            e.set_region_mode(mode)
+            for name, frames in contents:
+                run(e, name, frames)
+    with pkg.JpegTop(stream=torch.cuda.current_stream().cuda_stream) as e:  # automatic
+        for name, frames in (contents[0], contents[1], contents[1], contents[1], contents[2], contents[0], contents[0],
+                             contents[0]):
+            run(e, name, frames)
