@@ -193,7 +193,7 @@ int jpegenc_words_to_bytes(const uint32_t* words, const jpegenc_result* result, 
 /* Optional per-kernel timing with HIP events on the context's stream.  When enabled every kernel
  * launch is bracketed by events; jpegenc_kernel_times returns, per kernel, the number of launches
  * and the summed duration in ms since the last reset (this call synchronises the stream). */
-#define JPEGENC_N_KERNELS 4
+#define JPEGENC_N_KERNELS 5
 int jpegenc_set_profiling(jpegenc_ctx* ctx, int enable);
 int jpegenc_kernel_times(jpegenc_ctx* ctx, uint64_t launches[JPEGENC_N_KERNELS], double ms[JPEGENC_N_KERNELS],
                          int reset);

@@ -108,6 +108,8 @@ hipError_t launch_encode(const EncodeParams& p, uint32_t n_images, int align, hi
 hipError_t launch_scan(const ScanParams& p, uint32_t n_images, hipStream_t s);
 hipError_t launch_stuff_count(const StuffParams& p, uint32_t n_images, hipStream_t s);
 hipError_t launch_stuff_write(const StuffParams& p, uint32_t n_images, hipStream_t s);
+// count + write of whole images in one launch (one workgroup per image; for batches of many images)
+hipError_t launch_stuff_image(const StuffParams& p, uint32_t n_images, hipStream_t s);
 
 hipError_t launch_pad_edges(const uint8_t* src, int64_t stride, int64_t image_stride, int w, int h, int n_images,
                             uint8_t* dst, hipStream_t s);

@@ -899,18 +899,9 @@ __device__ __forceinline__ uint32_t wave_sum_before(const uint32_t* counts, uint
     return readlane_u32(wave_incl_scan_dpp(s), 63);
 }
 
-template <int SPEC>  // 1 KB steps requested before the chunk's length is known
-__global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_count(StuffParams p, uint32_t n_chunks) {
-    const int lane = threadIdx.x & 63;
-    const uint32_t gid = blockIdx.x * kStuffWaves + (threadIdx.x >> 6);
-    if (gid >= n_chunks) return;
-    const uint32_t* S = p.slots + (uint64_t)gid * kSlotWords;
-    // The first kStuffDepth steps' words are requested before the chunk's bit count and offset are known
-    // (their addresses depend on neither), so a photographic chunk costs one memory round trip, not one
-    // for the counts and one per step.  Words behind the chunk's end are read (the slot is always large
-    // enough) and ignored.
-    uint4 w[kStuffDepth];
-    uint32_t w4[kStuffDepth];
+// Requests the first SPEC 1 KB steps of a chunk stream: 16 bytes per lane and step plus the word behind them.
+template <int SPEC>
+__device__ __forceinline__ void request_chunk(const uint32_t* S, int lane, uint4 (&w)[kStuffDepth], uint32_t (&w4)[kStuffDepth]) {
 #pragma unroll
     for (int u = 0; u < kStuffDepth; ++u) {
         if (u < SPEC) {
@@ -919,23 +910,21 @@ __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_count(StuffParams p,
             w4[u] = q[4];
         }
     }
-    const uint32_t c = gid % p.cpi;
-    const uint32_t n = p.chunk_bits[gid] & kCountMask;
-    uint64_t o;
-    if (p.inline_scan) {  // uniform
-        o = wave_sum_before(p.chunk_bits + (gid - c), c, lane);
-        if (lane == 0) p.bit_off[gid] = o;
-        o += p.bit_base;
-    } else {
-        o = p.bit_off[gid] + p.bit_base;
-    }
+}
+
+// The 0xFF bytes owned by the chunk whose stream S (n bits) starts at bit o of the image's stream; pred8 = the
+// last 8 bits before it.  w, w4: the first SPEC steps as requested by request_chunk (left untouched when the
+// chunk has no more than kStuffDepth steps).  The same value in every lane.
+template <int SPEC>
+__device__ __forceinline__ uint32_t count_owned_ff(const uint32_t* S, uint4 (&w)[kStuffDepth], uint32_t (&w4)[kStuffDepth],
+                                                   uint32_t n, uint64_t o, uint32_t pred8, int lane) {
     const uint32_t sbits = (uint32_t)(o & 7u);  // bits of the first owned byte that lie in the predecessor
     const uint32_t A = (8u - sbits) & 7u;
     const uint32_t nbytes = (uint32_t)(((o + n) >> 3) - (o >> 3));
     const uint32_t nm = nbytes - (sbits ? 1u : 0u);  // owned bytes that lie entirely in this chunk
     uint32_t total = 0;
     if (sbits != 0 && lane == 0) {
-        const uint32_t pw = (c > 0) ? (p.chunk_bits[gid - 1] >> 24) : p.pred_tail8;
+        const uint32_t pw = pred8;
         const uint32_t sb = ((pw << A) | (readlane_u32(w[0].x, 0) >> (32u - A))) & 0xFFu;
         total = (sb == 0xFFu) ? 1u : 0u;
     }
@@ -972,6 +961,34 @@ __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_count(StuffParams p,
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d);
+    return total;
+}
+
+template <int SPEC>  // 1 KB steps requested before the chunk's length is known
+__global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_count(StuffParams p, uint32_t n_chunks) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t gid = blockIdx.x * kStuffWaves + (threadIdx.x >> 6);
+    if (gid >= n_chunks) return;
+    const uint32_t* S = p.slots + (uint64_t)gid * kSlotWords;
+    // The first kStuffDepth steps' words are requested before the chunk's bit count and offset are known
+    // (their addresses depend on neither), so a photographic chunk costs one memory round trip, not one
+    // for the counts and one per step.  Words behind the chunk's end are read (the slot is always large
+    // enough) and ignored.
+    uint4 w[kStuffDepth];
+    uint32_t w4[kStuffDepth];
+    request_chunk<SPEC>(S, lane, w, w4);
+    const uint32_t c = gid % p.cpi;
+    const uint32_t n = p.chunk_bits[gid] & kCountMask;
+    uint64_t o;
+    if (p.inline_scan) {  // uniform
+        o = wave_sum_before(p.chunk_bits + (gid - c), c, lane);
+        if (lane == 0) p.bit_off[gid] = o;
+        o += p.bit_base;
+    } else {
+        o = p.bit_off[gid] + p.bit_base;
+    }
+    const uint32_t pred8 = (c > 0) ? (p.chunk_bits[gid - 1] >> 24) : p.pred_tail8;
+    const uint32_t total = count_owned_ff<SPEC>(S, w, w4, n, o, pred8, lane);
     if (lane == 0) p.chunk_ff[gid] = total;
 }
 
@@ -982,28 +999,16 @@ __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_count(StuffParams p,
 // (one per wave) and leave it as whole words; the bytes of a word shared with a neighbouring chunk are
 // stored one by one.
 // ------------------------------------------------------------------------------------------------
+// Writes the stuffed bytes of one chunk (stream S of n bits at bit o of the image's stream, ff_before 0xFF bytes
+// owned by the chunks before it, pred8 = the last 8 bits before it) and, for the image's last chunk at end of
+// file, the result record.  w, w4: the first SPEC steps as requested by request_chunk when have_first (uniform),
+// else they are requested here.  `stage`: this wave's kStageBytes of LDS.
 template <int SPEC>
-__global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_write(StuffParams p, uint32_t n_chunks) {
-    __shared__ __attribute__((aligned(16))) uint8_t stage_all[kStuffWaves][kStageBytes];
-    uint8_t* const stage = stage_all[threadIdx.x >> 6];
-    const int lane = threadIdx.x & 63;
-    const uint32_t gid = blockIdx.x * kStuffWaves + (threadIdx.x >> 6);
-    if (gid >= n_chunks) return;
-    const uint32_t* S = p.slots + (uint64_t)gid * kSlotWords;
-    uint4 w[kStuffDepth];
-    uint32_t w4[kStuffDepth];
-#pragma unroll
-    for (int u = 0; u < kStuffDepth; ++u) {  // ahead of the counts and offsets, as in k_stuff_count
-        if (u < SPEC) {
-            const uint32_t* q = S + 256 * u + 4 * lane;
-            w[u] = *reinterpret_cast<const uint4*>(q);
-            w4[u] = q[4];
-        }
-    }
-    const uint32_t img = gid / p.cpi;
-    const uint32_t c = gid - img * p.cpi;
-    const uint32_t n = p.chunk_bits[gid] & kCountMask;
-    const uint64_t o = p.bit_off[gid] + p.bit_base;
+__device__ __forceinline__ void write_chunk(const StuffParams& p, const uint32_t* S, uint4 (&w)[kStuffDepth],
+                                            uint32_t (&w4)[kStuffDepth], bool have_first, uint8_t* const stage, uint32_t img,
+                                            uint32_t c, uint32_t gid, uint32_t n, uint64_t o, uint64_t ff_before,
+                                            uint32_t pred8, int lane) {
+    if (!have_first) request_chunk<SPEC>(S, lane, w, w4);  // (uniform)
     const uint64_t q_first = o >> 3;
     const uint32_t sbits = (uint32_t)(o & 7u);
     const uint32_t A = (8u - sbits) & 7u;
@@ -1013,14 +1018,13 @@ __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_write(StuffParams p,
     uint32_t* const out_words = p.words_out + (uint64_t)img * p.out_stride;
     uint8_t* const out_bytes = reinterpret_cast<uint8_t*>(out_words);
     const uint64_t cap_bytes = p.cap_words * 4;
-    const uint64_t ff_before = p.inline_scan ? (uint64_t)wave_sum_before(p.chunk_ff + (gid - c), c, lane) : p.ff_off[gid];
     const uint64_t pos0 = q_first + ff_before + p.ff_base;  // stuffed byte offset of the first owned byte
     uint64_t wbase = (pos0 >> 2) - p.out_word_base;             // index in out_words of stage[0]
     uint32_t head = (uint32_t)(pos0 & 3u);          // leading bytes of the stage's first word that belong to the previous chunk
     uint32_t fill = head;                           // bytes in the stage (uniform)
 
     if (sbits != 0) {  // the byte that begins in the predecessor: its last 8 bits travel with its bit count
-        const uint32_t pw = (c > 0) ? (p.chunk_bits[gid - 1] >> 24) : p.pred_tail8;
+        const uint32_t pw = pred8;
         const uint32_t sb = ((pw << A) | (readlane_u32(w[0].x, 0) >> (32u - A))) & 0xFFu;
         if (lane == 0) {
             stage[fill] = (uint8_t)sb;
@@ -1215,6 +1219,79 @@ __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_write(StuffParams p,
     }
 }
 
+template <int SPEC>
+__global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_write(StuffParams p, uint32_t n_chunks) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage_all[kStuffWaves][kStageBytes];
+    uint8_t* const stage = stage_all[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    const uint32_t gid = blockIdx.x * kStuffWaves + (threadIdx.x >> 6);
+    if (gid >= n_chunks) return;
+    const uint32_t* S = p.slots + (uint64_t)gid * kSlotWords;
+    uint4 w[kStuffDepth];
+    uint32_t w4[kStuffDepth];
+    request_chunk<SPEC>(S, lane, w, w4);  // ahead of the counts and offsets, as in k_stuff_count
+    const uint32_t img = gid / p.cpi;
+    const uint32_t c = gid - img * p.cpi;
+    const uint32_t n = p.chunk_bits[gid] & kCountMask;
+    const uint64_t o = p.bit_off[gid] + p.bit_base;
+    const uint64_t ff_before = p.inline_scan ? (uint64_t)wave_sum_before(p.chunk_ff + (gid - c), c, lane) : p.ff_off[gid];
+    const uint32_t pred8 = (c > 0) ? (p.chunk_bits[gid - 1] >> 24) : p.pred_tail8;
+    write_chunk<SPEC>(p, S, w, w4, true, stage, img, c, gid, n, o, ff_before, pred8, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_stuff_image: both stuffing steps for whole images in one launch, one workgroup of kImageWaves waves per
+// image.  The workgroup walks the image's chunks in order, kImageWaves at a time (one per wave): every wave
+// requests its chunk, works out its bit offset from the counts of the round's earlier chunks, counts its
+// 0xFF bytes, and after one barrier -- the counts of the round stand in LDS -- writes its stuffed bytes.
+// The running bit offset and 0xFF count stay in registers, so no prefix arrays, no scan launches, and each
+// chunk stream is read from memory once (a chunk of more than kStuffDepth steps: twice).  For batches of
+// many images (the host's threshold); fewer images keep k_stuff_count / k_stuff_write, whose grid covers the
+// chunks.  Both stuffing steps are bound by vector instructions (87 % of the write step's time), not by
+// memory, which is why reading the streams once buys so little.
+// ------------------------------------------------------------------------------------------------
+constexpr int kImageWaves = 16;
+
+template <int SPEC>
+__global__ __launch_bounds__(64 * kImageWaves) void k_stuff_image(StuffParams p) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage_all[kImageWaves][kStageBytes];
+    __shared__ uint32_t round_ff[2][kImageWaves];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint8_t* const stage = stage_all[wave];
+    const uint32_t img = blockIdx.x;
+    const uint32_t first = img * p.cpi;
+    uint64_t bits_before = p.bit_base, ff_before = 0;  // of the rounds done so far
+    uint32_t tail8_before = p.pred_tail8;              // last 8 bits before this round
+    for (uint32_t c0 = 0, r = 0; c0 < p.cpi; c0 += kImageWaves, ++r) {
+        const uint32_t c = c0 + wave;
+        const bool have = c < p.cpi;  // the image's last round may be short; its idle waves still meet the barrier
+        const uint32_t gid = first + (have ? c : p.cpi - 1u);
+        const uint32_t* S = p.slots + (uint64_t)gid * kSlotWords;
+        uint4 w[kStuffDepth];
+        uint32_t w4[kStuffDepth];
+        if (have) request_chunk<SPEC>(S, lane, w, w4);
+        // the round's bit counts: lane j holds chunk c0 + j
+        const uint32_t word = (lane < kImageWaves && c0 + lane < p.cpi) ? p.chunk_bits[first + c0 + lane] : 0u;
+        const uint32_t incl = wave_incl_scan_dpp(word & kCountMask);
+        const uint32_t n = readlane_u32(word, wave) & kCountMask;
+        const uint64_t o = bits_before + (readlane_u32(incl, wave) - n);
+        const uint32_t pred8 = wave ? (readlane_u32(word, wave - 1) >> 24) : tail8_before;
+        const bool one_pass = n <= 8u * 1024u * kStuffDepth - 64u;  // the requested steps cover it at any phase
+        uint32_t mine = 0;
+        if (have) mine = count_owned_ff<SPEC>(S, w, w4, n, o, pred8, lane);
+        if (lane == 0) round_ff[r & 1][wave] = mine;
+        __syncthreads();  // one barrier per round: the counts alternate between two rows
+        const uint32_t ffw = (lane < kImageWaves) ? round_ff[r & 1][lane] : 0u;
+        const uint32_t ffi = wave_incl_scan_dpp(ffw);
+        if (have)
+            write_chunk<SPEC>(p, S, w, w4, one_pass, stage, img, c, gid, n, o, ff_before + (readlane_u32(ffi, wave) - mine),
+                              pred8, lane);
+        bits_before += readlane_u32(incl, kImageWaves - 1);
+        ff_before += readlane_u32(ffi, kImageWaves - 1);
+        tail8_before = readlane_u32(word, kImageWaves - 1) >> 24;  // only read when another round follows: then this one was full
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_pad_edges: copies images of w x h pixels into images of w8 x h8 (the next multiples of 8), repeating
 // the last column and the last row.  An extension: jpeg_top has no edge handling (a block is 64
@@ -1312,6 +1389,15 @@ hipError_t launch_stuff_count(const StuffParams& p, uint32_t n_images, hipStream
         hipLaunchKernelGGL((k_stuff_count<kStuffDepth>), grid, block, 0, s, p, n_chunks);
     else
         hipLaunchKernelGGL((k_stuff_count<1>), grid, block, 0, s, p, n_chunks);
+    return hipGetLastError();
+}
+
+hipError_t launch_stuff_image(const StuffParams& p, uint32_t n_images, hipStream_t s) {
+    const dim3 grid(n_images), block(64 * kImageWaves);
+    if (p.spec_depth >= kStuffDepth)
+        hipLaunchKernelGGL((k_stuff_image<kStuffDepth>), grid, block, 0, s, p);
+    else
+        hipLaunchKernelGGL((k_stuff_image<1>), grid, block, 0, s, p);
     return hipGetLastError();
 }
 

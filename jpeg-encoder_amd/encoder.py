@@ -20,7 +20,7 @@ NOALLOC_MAX_CHUNKS = 2048
 HOST_PTRS, DEVICE_PTRS = 0, 1
 PAD_EDGES = 4
 SEG_CONTINUES = 2
-N_KERNELS = 4
+N_KERNELS = 5
 
 # every symbol include/jpegenc.h declares
 ABI_SYMBOLS = [

@@ -315,3 +315,56 @@ def test_region_modes_give_the_same_stream():
         for name, frames in (contents[0], contents[1], contents[1], contents[1], contents[2], contents[0], contents[0],
                              contents[0]):
             run(e, name, frames)
+
+
+def test_many_images_take_the_per_image_stuffing_kernel():
+    """From 512 images of at least 32 chunks on, one launch with one workgroup per image does both stuffing steps
+    (k_stuff_image).  520 images of 34 chunks (the last one partial) of every kind of content -- natural, noise
+    (chunk streams of more than five 1 KB steps), flat (the shortest possible chunks), all-ones bytes around
+    noise -- every one word for word against the oracle, and against the same batch coded in two halves (which
+    takes the per-chunk kernels)."""
+    pkg = load_pkg()
+    dev = torch.device("cuda:0")
+    h, w, n = 264, 520, 520
+    rng = np.random.default_rng(130)
+    imgs = np.empty((n, h, w, 3), np.uint8)
+    for i in range(n):
+        kind = i % 5
+        if kind == 0:
+            imgs[i] = natural_like(h, w, 2000 + i % 40)
+        elif kind == 1:
+            imgs[i] = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        elif kind == 2:
+            imgs[i] = rng.integers(0, 256, 3, dtype=np.uint8)  # flat
+        elif kind == 3:
+            imgs[i] = 255
+            imgs[i, 40:200, 100:400] = rng.integers(0, 256, (160, 300, 3), dtype=np.uint8)
+        else:
+            imgs[i] = imgs[i - 4]
+            imgs[i, :, 256:] = rng.choice(np.array([0, 255], dtype=np.uint8), size=(h, w - 256, 3))
+    d_in = torch.from_numpy(imgs).to(dev)
+    cap = pkg.max_words(w, h)
+    outs = []
+    with pkg.JpegTop(stream=torch.cuda.current_stream().cuda_stream) as e:
+        e.set_profiling(True)
+        for parts in ((0, n), (0, 260), (260, n)):
+            a, b = parts
+            d_words = torch.zeros((b - a, cap), dtype=torch.int32, device=dev)
+            d_res = torch.zeros((b - a, 32), dtype=torch.uint8, device=dev)
+            e.encode_batch_device(d_in[a:b].data_ptr(), b - a, w, h, w * 3, h * w * 3, d_words.data_ptr(), cap,
+                                  d_res.data_ptr())
+            torch.cuda.synchronize()
+            times = e.kernel_times(reset=True)
+            assert (times["k_stuff_image"][0] == 1) == (b - a >= 512) and (times["k_stuff_write"][0] == 1) == (b - a < 512)
+            outs.append((d_words.cpu().numpy().view(np.uint32), d_res.cpu().numpy().view(pkg.RESULT_DTYPE).reshape(b - a)))
+    words, res = outs[0]
+    halves_w = np.concatenate([outs[1][0], outs[2][0]])
+    halves_r = np.concatenate([outs[1][1], outs[2][1]])
+    assert res.tobytes() == halves_r.tobytes() and np.array_equal(words, halves_w)
+
+    def check(i):
+        k = int(res[i]["n_full_words"]) + (1 if res[i]["tail_bits"] else 0)
+        same_as_oracle(words[i, :k], res[i], imgs[i])
+
+    with ThreadPoolExecutor(8) as pool:
+        list(pool.map(check, range(n)))

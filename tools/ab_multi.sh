@@ -11,8 +11,9 @@ for flags in "$@"; do
 import json, sys
 l = [x for x in open("gpurun_out/abm.log") if x.startswith("{")][-1]
 d = json.loads(l); k = d["kernel_ms_per_step"]
-print("%-5s %-44s %9.0f Mpx/s %8.3f ms  enc %.3f cnt %.3f wr %.3f  %.3f B/px" % (
-    sys.argv[1], sys.argv[2], d["value"], d["ms_per_step"], k["k_encode_chunks"], k["k_stuff_count"], k["k_stuff_write"], d["out_bytes_per_pixel"]))
+print("%-5s %-44s %9.0f Mpx/s %8.3f ms  enc %.3f cnt %.3f wr %.3f img %.3f  %.3f B/px" % (
+    sys.argv[1], sys.argv[2], d["value"], d["ms_per_step"], k["k_encode_chunks"], k["k_stuff_count"], k["k_stuff_write"],
+    k.get("k_stuff_image", 0.0), d["out_bytes_per_pixel"]))
 PY
   done
 done
