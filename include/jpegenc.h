@@ -211,8 +211,9 @@ int jpegenc_set_workspace_limit(jpegenc_ctx* ctx, size_t bytes);
  * twelve wavefronts share a compute unit and are right for photographic content up to about 2 bytes per
  * pixel; a group of 64 blocks that holds a longer block is coded twice.  Large regions (2016 bits) never
  * need that below about 3.9 bytes per pixel and cost 9 % where small ones suffice.  AUTO (default): the
- * kernel counts the groups with a too-long block in every launch and the context switches when, in the
- * launches before, more than 12 % (back: fewer than 6 %) of the groups had one. */
+ * kernel counts, in every launch, the groups with a block too long for a small and for a large region, and
+ * the context uses for the next launches whichever size those counts make cheaper (from about 12 % of the
+ * groups too long for small regions on: large; content like uniform noise, too long for both: small). */
 #define JPEGENC_REGIONS_AUTO 0
 #define JPEGENC_REGIONS_SMALL 1
 #define JPEGENC_REGIONS_LARGE 2

@@ -302,14 +302,19 @@ int choose_regions(jpegenc_ctx* ctx, EncodeParams* ep, int align) {
     if (ctx->region_mode == JPEGENC_REGIONS_AUTO) {
         // whatever the last completed copy left in the pinned words: a heuristic, any value is safe
         const volatile uint32_t* h = ctx->stats_host;
-        uint64_t over = 0;
-        for (int i = 0; i < 16; ++i) over += h[16 * i];
+        uint64_t over_small = 0, over_large = 0;
+        for (int i = 0; i < 16; ++i) {
+            over_small += h[16 * i];
+            over_large += h[16 * i + 1];
+        }
         const uint64_t total = h[16 * 16];
-        if (total >= 256 && over <= total) {
-            // A chunk with such an MCU costs a second pass with small regions; large regions cost every
-            // chunk about 9 % (two waves per SIMD instead of three).
-            if (!ctx->large_regions && over * 100 > total * 12) ctx->large_regions = true;
-            if (ctx->large_regions && over * 100 < total * 6) ctx->large_regions = false;
+        if (total >= 256 && over_large <= over_small && over_small <= total) {
+            // A chunk with an MCU too long for its region costs a second pass; large regions cost every chunk
+            // about 9 % (two waves per SIMD instead of three).  Per 100 chunks: 100 + over_small passes against
+            // 109 + 1.09 over_large; the margins keep a launch near the break-even from flipping back and forth.
+            const uint64_t small_cost = 100 * (total + over_small), large_cost = 109 * (total + over_large);
+            if (!ctx->large_regions && small_cost * 100 > large_cost * 103) ctx->large_regions = true;
+            if (ctx->large_regions && small_cost * 103 < large_cost * 100) ctx->large_regions = false;
         }
     } else {
         ctx->large_regions = ctx->region_mode == JPEGENC_REGIONS_LARGE;

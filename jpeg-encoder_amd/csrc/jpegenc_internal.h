@@ -63,7 +63,8 @@ struct EncodeParams {
     const int32_t* qmul;   // [3][64] multipliers 4096/Q in Huffman-input order, or nullptr
     uint32_t* stats;       // [kEncodeStatsWords] or nullptr: per launch, zeroed by the host before it; words
                            // 0, 16, ..., 240 count the chunks that hold an MCU too long for a small LDS region,
-                           // word 256 receives the launch's chunk count
+                           // words 1, 17, ..., 241 those with one too long even for a large region, word 256
+                           // receives the launch's chunk count
     uint32_t large_regions;  // 1: the kernel variant with large LDS regions (8 workgroups per CU instead of 12)
 };
 constexpr int kEncodeStatsWords = 16 * 16 + 16;

@@ -508,6 +508,7 @@ __device__ __forceinline__ int halo_dc(int sample, bool luma, int qm0, bool do_q
 // different LDS banks.
 [[maybe_unused]] constexpr int kRegionSmall = 41, kRegionLarge = 65;
 constexpr uint32_t kSmallRegionBits = (kRegionSmall - 2) * 32;  // what a lane may emit in a small region
+constexpr uint32_t kLargeRegionBits = (kRegionLarge - 2) * 32;
 
 // End of the range of lanes [lo, hi) that one exact-fit pass can hold: `need_incl` is the inclusive prefix
 // sum of the lanes' region sizes, `before_lo` the sum over the lanes before `lo`.
@@ -692,8 +693,12 @@ __global__ __launch_bounds__(64, REGION > kRegionSmall ? 2 : 3) void k_encode_ch
         if (!fit && p.stats) {
             // for the host's choice of REGION: chunks with an MCU beyond the small region, spread over 16
             // counters on lines of their own, and the launch's chunk count beside them
-            if (__any((int)(Lall > kSmallRegionBits)) && lane == 0)
-                __hip_atomic_fetch_add(&p.stats[(gid & 15u) * 16u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__any((int)(Lall > kSmallRegionBits))) {
+                if (lane == 0)
+                    __hip_atomic_fetch_add(&p.stats[(gid & 15u) * 16u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__any((int)(Lall > kLargeRegionBits)) && lane == 0)  // ... and even for a large one
+                    __hip_atomic_fetch_add(&p.stats[(gid & 15u) * 16u + 1u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             if (gid == 0 && lane == 0) p.stats[16 * 16] = p.n_images * p.cpi;
         }
         if (!fit && __any((int)(Lall > cap * 32u))) {

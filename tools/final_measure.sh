@@ -8,5 +8,5 @@ timeout -k 10 300 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/fi
 cut -c1-400 gpurun_out/final_bench.json
 cd /tmp && timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/final_trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu > $GRAFT_REPO_ROOT/gpurun_out/final_trace.log 2>&1 || { tail -5 $GRAFT_REPO_ROOT/gpurun_out/final_trace.log; exit 1; }
 cd $GRAFT_REPO_ROOT
-bash tools/pmc_pass.sh fetch FETCH_SIZE | grep -A2 k_encode
-bash tools/pmc_pass.sh write WRITE_SIZE | grep -A2 k_encode
+bash tools/pmc_pass.sh fetch FETCH_SIZE | grep -A1 jpegenc
+bash tools/pmc_pass.sh write WRITE_SIZE | grep -A1 jpegenc
