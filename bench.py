@@ -46,6 +46,9 @@ def parse_args():
     ap.add_argument("--ws-mb", type=int, default=0, help="workspace limit in MiB (0: library default)")
     ap.add_argument("--regions", choices=["auto", "small", "large"], default="auto",
                     help="LDS staging regions of the encode kernel (jpegenc_set_region_mode)")
+    ap.add_argument("--split", action="store_true", help="separate kernels also for small calls (jpegenc_set_pipeline)")
+    ap.add_argument("--sync-each-step", action="store_true",
+                    help="wait for every step before the next is queued: the latency of one call, not the rate of a queue of them")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     return ap.parse_args()
@@ -169,11 +172,15 @@ def main():
     if args.ws_mb:
         enc.set_workspace_limit(args.ws_mb << 20)
     enc.set_region_mode({"auto": enc.REGIONS_AUTO, "small": enc.REGIONS_SMALL, "large": enc.REGIONS_LARGE}[args.regions])
+    if args.split:
+        enc.set_pipeline(enc.PIPELINE_SPLIT)
     enc.reserve(nf, w, h)  # the steps below only enqueue work
 
     def step():
         enc.encode_batch_device(frames.data_ptr(), nf, w, h, w * 3, h * w * 3, words.data_ptr(), cap_words,
                                 results.data_ptr())
+        if args.sync_each_step:
+            enc.synchronize()
 
     def barrier():
         if world > 1:

@@ -206,6 +206,16 @@ const char* jpegenc_kernel_name(int index);
  * sub-batches are halved until they fit; JPEGENC_E_NOMEM when not even one image does. */
 int jpegenc_set_workspace_limit(jpegenc_ctx* ctx, size_t bytes);
 
+/* Launch structure.  No counterpart in jpeg_top and no effect on the output.  AUTO (default): a call of at
+ * most 2048 groups of 64 blocks (four 1080p frames) with all-ones tables and 8-byte-aligned rows runs as ONE
+ * kernel launch -- every group's wavefront waits for the bit and 0xFF counts of the groups before it, then
+ * stuffs and writes its own part of the stream (a wavefront that waits in vain for a tenth of a second gives
+ * up and the image's status becomes JPEGENC_E_HIP); everything else runs as separate kernels (encode, prefix
+ * sums, 0xFF count, stuff + write).  SPLIT: always the separate kernels. */
+#define JPEGENC_PIPELINE_AUTO 0
+#define JPEGENC_PIPELINE_SPLIT 1
+int jpegenc_set_pipeline(jpegenc_ctx* ctx, int mode);
+
 /* How the encode kernel sizes the per-block staging regions in LDS.  No counterpart in jpeg_top and no
  * effect on the output: only on speed.  Small regions (1248 bits per block of Y, Cb and Cr together) let
  * twelve wavefronts share a compute unit and are right for photographic content up to about 2 bytes per

@@ -1,6 +1,7 @@
 // jpegenc_host.cpp -- C ABI of libjpegenc.so (include/jpegenc.h): context, workspace, launch sequencing.
 // The compute path is the HIP kernels in jpegenc_kernels.hip; there is no CPU fallback in this library.
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -114,6 +115,10 @@ struct jpegenc_ctx {
     bool large_regions = false;
     DevBuf<uint32_t> stats;
     uint32_t* stats_host = nullptr;
+
+    // Single-launch form of small launches (jpegenc_set_pipeline): hand-off words of the chunks, 3 per chunk
+    int pipeline = JPEGENC_PIPELINE_AUTO;
+    DevBuf<uint64_t> state;
 
     // jpegenc_encode_batch_noalloc: this device's copy of the library's static workspace
     uint8_t* static_ws = nullptr;
@@ -295,10 +300,16 @@ int workspace_used(jpegenc_ctx* ctx) {
 
 // Region size for the next launch of the encode kernel, and its statistics buffer (zeroed on the stream).  Only
 // the common kernel variant (8-byte-aligned rows, all-ones tables) exists with large regions.
-int choose_regions(jpegenc_ctx* ctx, EncodeParams* ep, int align) {
+int choose_regions(jpegenc_ctx* ctx, EncodeParams* ep, int align, uint64_t chunks) {
     ep->stats = nullptr;
     ep->large_regions = 0;
     if (ctx->quant || align < 8) return JPEGENC_OK;
+    if (chunks <= kSingleLaunchMaxChunks && ctx->region_mode == JPEGENC_REGIONS_AUTO) {
+        // every chunk is resident at once even with large regions: they cost nothing here, and a small call is
+        // spared the two stream operations of the statistics
+        ep->large_regions = 1;
+        return JPEGENC_OK;
+    }
     if (ctx->region_mode == JPEGENC_REGIONS_AUTO) {
         // whatever the last completed copy left in the pinned words: a heuristic, any value is safe
         const volatile uint32_t* h = ctx->stats_host;
@@ -332,6 +343,16 @@ int collect_stats(jpegenc_ctx* ctx, const EncodeParams& ep) {
     return JPEGENC_OK;
 }
 
+// Tag of a single-launch call in its hand-off words: unique in the process (contexts may share the static
+// workspace's neighbourhood in time, and a word left by any earlier launch must read as "not there yet").
+uint32_t next_generation() {
+    static std::atomic<uint32_t> counter{0};
+    uint32_t g;
+    do g = counter.fetch_add(1, std::memory_order_relaxed) + 1;
+    while (g == 0);
+    return g;
+}
+
 // The launches for n images (one launch group) with the workspace `ws`.  All pointers are device memory.
 // `timed`: bracket the kernels with events when profiling is on (creates events).
 int run_group(jpegenc_ctx* ctx, const Workspace& ws, bool timed, const Plan& pl, const uint8_t* rgb, uint32_t n,
@@ -357,7 +378,24 @@ int run_group(jpegenc_ctx* ctx, const Workspace& ws, bool timed, const Plan& pl,
     ep.chunk_bits = ws.chunk_bits;
     ep.htab = ctx->htab.p;
     ep.qmul = ctx->quant ? ctx->qmul.p : nullptr;
-    int rc_regions = choose_regions(ctx, &ep, align);
+    ep.state = nullptr;
+    ep.generation = 0;
+    ep.words_out = words;
+    ep.out_stride = cap_words;
+    ep.cap_words = cap_words;
+    ep.results = results;
+    // A frame or a few (every chunk resident at once), common kernel variant: one launch does it all -- each
+    // chunk's wave waits for the counts of the chunks before it, then stuffs and writes its own stream.
+    if (ctx->pipeline == JPEGENC_PIPELINE_AUTO && uint64_t(n) * cpi <= kSingleLaunchMaxChunks && !ctx->quant && align >= 8) {
+        ep.stats = nullptr;
+        ep.large_regions = 1;
+        ep.state = ctx->state.p;
+        ep.generation = next_generation();
+        ProfScope ps(ctx, K_ENCODE);
+        HIPCHK(ctx, launch_encode(ep, n, align, ctx->stream));
+        return JPEGENC_OK;
+    }
+    int rc_regions = choose_regions(ctx, &ep, align, uint64_t(n) * cpi);
     if (rc_regions != JPEGENC_OK) return rc_regions;
     {
         ProfScope ps(ctx, K_ENCODE);
@@ -574,6 +612,8 @@ int jpegenc_create(jpegenc_ctx** out, const jpegenc_config* cfg) {
     e = ctx->htab.reserve(kHtabEntries);
     if (e == hipSuccess) e = ctx->qmul.reserve(3 * 64);
     if (e == hipSuccess) e = ctx->stats.reserve(kEncodeStatsWords);
+    if (e == hipSuccess) e = ctx->state.reserve(3 * size_t(kSingleLaunchMaxChunks));
+    if (e == hipSuccess) e = hipMemset(ctx->state.p, 0, 3 * size_t(kSingleLaunchMaxChunks) * sizeof(uint64_t));
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&ctx->stats_host), kEncodeStatsWords * 4, hipHostMallocDefault);
     if (e == hipSuccess) std::memset(ctx->stats_host, 0, kEncodeStatsWords * 4);
     if (e == hipSuccess) e = hipMemcpy(ctx->htab.p, htab, sizeof htab, hipMemcpyHostToDevice);
@@ -598,6 +638,7 @@ int jpegenc_destroy(jpegenc_ctx* ctx) {
     ctx->htab.release();
     ctx->qmul.release();
     ctx->stats.release();
+    ctx->state.release();
     if (ctx->stats_host) (void)hipHostFree(ctx->stats_host);
     ctx->slots.release();
     ctx->chunk_bits.release();
@@ -808,8 +849,13 @@ int jpegenc_segment_encode(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int rows
     ep.htab = ctx->htab.p;
     ep.qmul = ctx->quant ? ctx->qmul.p : nullptr;
     // the block row above must be as aligned as the segment's own rows: the stride takes care of that
+    ep.state = nullptr;
+    ep.generation = 0;
+    ep.words_out = nullptr;
+    ep.out_stride = ep.cap_words = 0;
+    ep.results = nullptr;
     const int seg_align = pointer_align(d_rgb, d_stride, 0, 1, rows);
-    int rc_regions = choose_regions(ctx, &ep, seg_align);
+    int rc_regions = choose_regions(ctx, &ep, seg_align, cpi);
     if (rc_regions != JPEGENC_OK) return rc_regions;
     HIPCHK(ctx, launch_encode(ep, 1, seg_align, ctx->stream));
     rc_regions = collect_stats(ctx, ep);
@@ -1026,6 +1072,12 @@ int jpegenc_kernel_times(jpegenc_ctx* ctx, uint64_t launches[JPEGENC_N_KERNELS],
 
 const char* jpegenc_kernel_name(int index) {
     return (index >= 0 && index < JPEGENC_N_KERNELS) ? kKernelNames[index] : "";
+}
+
+int jpegenc_set_pipeline(jpegenc_ctx* ctx, int mode) {
+    if (!ctx || (mode != JPEGENC_PIPELINE_AUTO && mode != JPEGENC_PIPELINE_SPLIT)) return JPEGENC_E_BAD_ARG;
+    ctx->pipeline = mode;
+    return JPEGENC_OK;
 }
 
 int jpegenc_set_region_mode(jpegenc_ctx* ctx, int mode) {

@@ -66,7 +66,19 @@ struct EncodeParams {
                            // words 1, 17, ..., 241 those with one too long even for a large region, word 256
                            // receives the launch's chunk count
     uint32_t large_regions;  // 1: the kernel variant with large LDS regions (8 workgroups per CU instead of 12)
+    // Single-launch form (small launches only, `state` != nullptr): every chunk's wave goes on to find its place
+    // in the image's stream from the hand-off words of the chunks before it, stuffs its stream and writes the
+    // words.  state = [3][n_images * cpi] words of tag << 32 | payload, tag = `generation` (never 0, never reused:
+    // words of earlier launches read as "not there yet", so the array needs no clearing).
+    uint64_t* state;
+    uint32_t generation;
+    uint32_t* words_out;      // as in StuffParams
+    uint64_t out_stride;
+    uint64_t cap_words;
+    jpegenc_result* results;
 };
+// Largest launch that takes the single-launch form: all its chunks are resident at once (256 CUs x 8 workgroups).
+constexpr uint32_t kSingleLaunchMaxChunks = 2048;
 constexpr int kEncodeStatsWords = 16 * 16 + 16;
 
 struct ScanParams {

@@ -496,6 +496,370 @@ __device__ __forceinline__ int halo_dc(int sample, bool luma, int qm0, bool do_q
 }
 
 // ------------------------------------------------------------------------------------------------
+// Stuffing helpers, shared by the stuffing kernels and by the single-launch form of the encode kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kCountMask = 0xFFFFFFu;  // counts live in the low 24 bits of their words
+[[maybe_unused]] constexpr int kStageBytes = 2048 + 64;  // one step: <= 1024 bytes, doubled by stuffing, + residual
+
+[[maybe_unused]] constexpr int kStuffWaves = 4;  // independent waves per workgroup, one chunk each
+constexpr int kStuffDepth = 5;  // steps whose loads are in flight together
+
+// bit 7 of every byte of the result is set iff that byte of v is 0xFF: the low seven bits plus one carry
+// into bit 7 exactly when they are all ones, and never beyond the byte
+__device__ __forceinline__ uint32_t ff_flags(uint32_t v) {
+    const uint32_t t = (v & 0x7F7F7F7Fu) + 0x01010101u;
+    return t & v & 0x80808080u;
+}
+
+// Requests the first SPEC 1 KB steps of a chunk stream: 16 bytes per lane and step plus the word behind them.
+template <int SPEC>
+__device__ __forceinline__ void request_chunk(const uint32_t* S, int lane, uint4 (&w)[kStuffDepth], uint32_t (&w4)[kStuffDepth]) {
+#pragma unroll
+    for (int u = 0; u < kStuffDepth; ++u) {
+        if (u < SPEC) {
+            const uint32_t* q = S + 256 * u + 4 * lane;
+            w[u] = *reinterpret_cast<const uint4*>(q);
+            w4[u] = q[4];
+        }
+    }
+}
+
+// The 0xFF bytes owned by the chunk whose stream S (n bits) starts at bit o of the image's stream; pred8 = the
+// last 8 bits before it.  w, w4: the first SPEC steps as requested by request_chunk (left untouched when the
+// chunk has no more than kStuffDepth steps).  The same value in every lane.
+template <int SPEC>
+__device__ __forceinline__ uint32_t count_owned_ff(const uint32_t* S, uint4 (&w)[kStuffDepth], uint32_t (&w4)[kStuffDepth],
+                                                   uint32_t n, uint64_t o, uint32_t pred8, int lane) {
+    const uint32_t sbits = (uint32_t)(o & 7u);  // bits of the first owned byte that lie in the predecessor
+    const uint32_t A = (8u - sbits) & 7u;
+    const uint32_t nbytes = (uint32_t)(((o + n) >> 3) - (o >> 3));
+    const uint32_t nm = nbytes - (sbits ? 1u : 0u);  // owned bytes that lie entirely in this chunk
+    uint32_t total = 0;
+    if (sbits != 0 && lane == 0) {
+        const uint32_t pw = pred8;
+        const uint32_t sb = ((pw << A) | (readlane_u32(w[0].x, 0) >> (32u - A))) & 0xFFu;
+        total = (sb == 0xFFu) ? 1u : 0u;
+    }
+    for (uint32_t pass = 0; pass < nm; pass += 1024 * kStuffDepth) {
+#pragma unroll
+        for (int u = 0; u < kStuffDepth; ++u) {  // what was not requested ahead
+            const uint32_t* q = S + ((pass >> 2) + 256 * u) + 4 * lane;
+            if ((pass != 0 || u >= SPEC) && pass + 1024u * u < nm) {  // uniform
+                w[u] = *reinterpret_cast<const uint4*>(q);
+                w4[u] = q[4];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kStuffDepth; ++u) {
+            const uint32_t base = pass + 1024u * u;
+            if (base < nm) {  // uniform
+                uint32_t v0 = w[u].x, v1 = w[u].y, v2 = w[u].z, v3 = w[u].w;
+                if (A != 0) {  // uniform
+                    v0 = __builtin_amdgcn_alignbit(w[u].x, w[u].y, 32u - A);
+                    v1 = __builtin_amdgcn_alignbit(w[u].y, w[u].z, 32u - A);
+                    v2 = __builtin_amdgcn_alignbit(w[u].z, w[u].w, 32u - A);
+                    v3 = __builtin_amdgcn_alignbit(w[u].w, w4[u], 32u - A);
+                }
+                uint32_t m0 = ff_flags(v0), m1 = ff_flags(v1), m2 = ff_flags(v2), m3 = ff_flags(v3);
+                if (base + 1024 > nm) {  // uniform: the last step, some bytes lie behind the chunk's last whole byte
+                    const uint32_t j = base + 16u * (uint32_t)lane;
+                    const int nv = (j < nm) ? (int)min(16u, nm - j) : 0;
+                    auto keep = [&](int nb) { return nb >= 4 ? 0xFFFFFFFFu : nb <= 0 ? 0u : ~(0xFFFFFFFFu >> (8 * nb)); };
+                    m0 &= keep(nv); m1 &= keep(nv - 4); m2 &= keep(nv - 8); m3 &= keep(nv - 12);
+                }
+                total += __popc(m0) + __popc(m1) + __popc(m2) + __popc(m3);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d);
+    return total;
+}
+
+// Writes the stuffed bytes of one chunk (stream S of n bits at bit o of the image's stream, ff_before 0xFF bytes
+// owned by the chunks before it, pred8 = the last 8 bits before it) and, for the image's last chunk at end of
+// file, the result record (prev_known: the previous chunk's bit count and last 32 bits come as arguments, else
+// they are read from its slot when the tail word needs them).  w, w4: the first SPEC steps as requested by request_chunk when have_first (uniform),
+// else they are requested here.  `stage`: this wave's kStageBytes of LDS.
+template <int SPEC>
+__device__ __forceinline__ void write_chunk(const StuffParams& p, const uint32_t* S, uint4 (&w)[kStuffDepth],
+                                            uint32_t (&w4)[kStuffDepth], bool have_first, uint8_t* const stage, uint32_t img,
+                                            uint32_t c, uint32_t gid, uint32_t n, uint64_t o, uint64_t ff_before,
+                                            uint32_t pred8, int lane, bool prev_known = false, uint32_t prev_bits = 0,
+                                            uint32_t prev_tail32 = 0) {
+    if (!have_first) request_chunk<SPEC>(S, lane, w, w4);  // (uniform)
+    const uint64_t q_first = o >> 3;
+    const uint32_t sbits = (uint32_t)(o & 7u);
+    const uint32_t A = (8u - sbits) & 7u;
+    const uint32_t nbytes = (uint32_t)(((o + n) >> 3) - q_first);
+    const uint32_t nm = nbytes - (sbits ? 1u : 0u);
+
+    uint32_t* const out_words = p.words_out + (uint64_t)img * p.out_stride;
+    uint8_t* const out_bytes = reinterpret_cast<uint8_t*>(out_words);
+    const uint64_t cap_bytes = p.cap_words * 4;
+    const uint64_t pos0 = q_first + ff_before + p.ff_base;  // stuffed byte offset of the first owned byte
+    uint64_t wbase = (pos0 >> 2) - p.out_word_base;             // index in out_words of stage[0]
+    uint32_t head = (uint32_t)(pos0 & 3u);          // leading bytes of the stage's first word that belong to the previous chunk
+    uint32_t fill = head;                           // bytes in the stage (uniform)
+
+    if (sbits != 0) {  // the byte that begins in the predecessor: its last 8 bits travel with its bit count
+        const uint32_t pw = pred8;
+        const uint32_t sb = ((pw << A) | (readlane_u32(w[0].x, 0) >> (32u - A))) & 0xFFu;
+        if (lane == 0) {
+            stage[fill] = (uint8_t)sb;
+            stage[fill + 1] = 0;
+        }
+        fill += (sb == 0xFFu) ? 2u : 1u;
+    }
+
+    auto flush = [&](bool final_pad) {
+        // stores the complete words of the stage, four per lane and turn; keeps the residual bytes for
+        // the next step
+        const uint32_t nwords = final_pad ? ((fill + 3u) >> 2) : (fill >> 2);
+        for (uint32_t i = 4u * lane; i < nwords; i += 256) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(stage + 4 * i);
+            const uint64_t gw = wbase + i;
+            const uint32_t t[4] = {__builtin_bswap32(raw.x), __builtin_bswap32(raw.y), __builtin_bswap32(raw.z),
+                                   __builtin_bswap32(raw.w)};
+            if (i + 4 <= nwords && gw + 4 <= p.cap_words && !(i == 0 && head)) {
+                __builtin_memcpy(out_words + gw, t, 16);  // word-aligned 16-byte store
+            } else {
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    if (i + k >= nwords) break;
+                    if (i + k == 0 && head) {  // word shared with the previous chunk: only our bytes
+                        for (uint32_t b = head; b < 4; ++b) {
+                            const uint64_t ga = gw * 4 + b;
+                            if (ga < cap_bytes) out_bytes[ga ^ 3] = stage[b];
+                        }
+                    } else if (gw + k < p.cap_words) {
+                        out_words[gw + k] = t[k];
+                    }
+                }
+            }
+        }
+        wave_sync();
+        if (nwords) {
+            const uint32_t rest = final_pad ? 0u : (fill & 3u);
+            if (lane < rest) stage[lane] = stage[nwords * 4 + lane];  // reads and writes are disjoint words
+            wbase += nwords;
+            fill = rest;
+            head = 0;
+        }
+        wave_sync();
+    };
+
+    // One word holding at least one 0xFF (flags m), all four bytes valid, to stage offset `at`.  Every byte
+    // goes out as the pair (byte, 0x00): the zero is the stuffing when the byte is 0xFF and is
+    // overwritten by the next byte's pair otherwise.  The last byte of a lane's last word must not
+    // write beyond the lane's bytes: it is stored alone unless it is 0xFF.
+    auto ff_word = [&](uint32_t at, uint32_t v, uint32_t m, bool lane_end) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint16_t pair = (uint16_t)((v >> (24 - 8 * b)) & 0xFFu);
+            const uint32_t f = (m >> (31 - 8 * b)) & 1u;
+            if (b < 3 || !lane_end || f)
+                __builtin_memcpy(&stage[at], &pair, 2);
+            else
+                stage[at] = (uint8_t)pair;
+            at += 1u + f;
+        }
+    };
+
+    for (uint32_t pass = 0; pass < nm; pass += 1024 * kStuffDepth) {
+#pragma unroll
+        for (int u = 0; u < kStuffDepth; ++u) {  // what was not requested ahead
+            const uint32_t* q = S + ((pass >> 2) + 256 * u) + 4 * lane;
+            if ((pass != 0 || u >= SPEC) && pass + 1024u * u < nm) {  // uniform
+                w[u] = *reinterpret_cast<const uint4*>(q);
+                w4[u] = q[4];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kStuffDepth; ++u) {
+            const uint32_t base = pass + 1024u * u;
+            if (base >= nm) break;  // uniform
+            const uint32_t j = base + 16u * (uint32_t)lane;
+            const int nvalid = (j < nm) ? (int)min(16u, nm - j) : 0;
+            uint32_t v[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+            if (A != 0) {  // uniform
+                v[0] = __builtin_amdgcn_alignbit(w[u].x, w[u].y, 32u - A);
+                v[1] = __builtin_amdgcn_alignbit(w[u].y, w[u].z, 32u - A);
+                v[2] = __builtin_amdgcn_alignbit(w[u].z, w[u].w, 32u - A);
+                v[3] = __builtin_amdgcn_alignbit(w[u].w, w4[u], 32u - A);
+            }
+            uint32_t m[4] = {ff_flags(v[0]), ff_flags(v[1]), ff_flags(v[2]), ff_flags(v[3])};
+            const bool partial = base + 1024 > nm;  // uniform: the chunk's last step, some lanes hold fewer than 16 bytes
+            if (partial) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int nb = nvalid - 4 * i;  // valid bytes of word i
+                    m[i] &= nb >= 4 ? 0xFFFFFFFFu : nb <= 0 ? 0u : ~(0xFFFFFFFFu >> (8 * nb));
+                }
+            }
+            const uint32_t cnt = __popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]);
+            const uint32_t incl = wave_incl_scan_dpp(cnt);
+            const uint32_t it_ff = readlane_u32(incl, 63);
+            uint32_t a = fill + 16u * (uint32_t)lane + (incl - cnt);  // stage offset of this lane's first byte
+            if (nvalid == 16 && cnt == 0) {
+                uint32_t t[4] = {__builtin_bswap32(v[0]), __builtin_bswap32(v[1]), __builtin_bswap32(v[2]),
+                                 __builtin_bswap32(v[3])};
+                __builtin_memcpy(&stage[a], t, 16);  // byte-aligned 16-byte store
+            } else if (nvalid == 16) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (m[i] == 0) {
+                        const uint32_t t = __builtin_bswap32(v[i]);
+                        __builtin_memcpy(&stage[a], &t, 4);
+                    } else {
+                        ff_word(a, v[i], m[i], i == 3);
+                    }
+                    a += 4u + __popc(m[i]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int nb = nvalid - 4 * i;
+                    for (int b = 0; b < 4 && b < nb; ++b) {
+                        stage[a++] = (uint8_t)(v[i] >> (24 - 8 * b));
+                        if (m[i] & (0x80000000u >> (8 * b))) stage[a++] = 0;
+                    }
+                }
+            }
+            fill += min(1024u, nm - base) + it_ff;
+            wave_sync();
+            flush(false);
+        }
+    }
+
+    const bool last = (c == p.cpi - 1) && p.eof;
+    if (!last) {
+        // bytes after the last whole word belong to a word shared with the next chunk
+        if ((uint32_t)lane >= head && (uint32_t)lane < fill) {
+            const uint64_t ga = wbase * 4 + lane;
+            if (ga < cap_bytes) out_bytes[ga ^ 3] = stage[lane];
+        }
+    } else {
+        // end of file: the incomplete last byte is never stuffed; the residual bits are presented
+        // left-aligned in one more word with their count (ff_checker.sv:289-360, functional)
+        const uint64_t total_bits = o + n;
+        const uint32_t rem = (uint32_t)(total_bits & 7u);
+        const uint64_t stuffed_bytes = (wbase + p.out_word_base) * 4 + fill;
+        if (lane == 0) {
+            if (head != 0 && c > 0) {
+                // Nothing has left the stage yet and its first word is shared with the previous chunk, so
+                // the word reported as tail_word may be that one: fetch the previous chunk's last `head`
+                // stuffed bytes (its last three owned bytes with their stuffing suffice) into the stage.
+                // They are only read here; in memory that chunk writes them itself.
+                // (bits [np - sbits - 24, np - sbits) of the previous chunk's np bits, in the top 24 bits of w32: from
+                // its slot, or from its last 32 bits when the caller has them at hand)
+                uint32_t w32;
+                if (prev_known) {
+                    w32 = (prev_tail32 >> sbits) << 8;
+                } else {
+                    const uint32_t np = p.chunk_bits[gid - 1] & kCountMask;
+                    const uint32_t* Sp = S - kSlotWords;
+                    const uint32_t l = np - sbits - 24u, wi = l >> 5, sh = l & 31u;
+                    w32 = sh ? __builtin_amdgcn_alignbit(Sp[wi], Sp[wi + 1], 32u - sh) : Sp[wi];
+                }
+                uint32_t seq = 0;  // the last stuffed bytes, newest in the low byte
+                for (int k = 2; k >= 0; --k) {
+                    const uint32_t b = (w32 >> (8 + 8 * k)) & 0xFFu;
+                    seq = (seq << 8) | b;
+                    if (b == 0xFFu) seq <<= 8;
+                }
+                for (uint32_t k = 0; k < head; ++k) stage[k] = (uint8_t)(seq >> (8 * (head - 1 - k)));
+            } else if (head != 0) {
+                // a one-chunk segment whose first word begins in the segment before it: those bytes are the
+                // neighbour's and read as zero here, like the ones it leaves zero in memory
+                for (uint32_t k = 0; k < head; ++k) stage[k] = 0;
+            }
+            uint32_t f = fill;
+            if (rem) {
+                // the last rem bits of the chunk stream, left-aligned in a byte
+                const uint32_t l = n - rem, wi = l >> 5, sh = l & 31u;
+                const uint32_t w32 = sh ? __builtin_amdgcn_alignbit(S[wi], S[wi + 1], 32u - sh) : S[wi];
+                const uint32_t vb = w32 >> 24;
+                stage[f++] = (uint8_t)(vb & (0xFFu << (8u - rem)));
+            }
+            while (f & 3u) stage[f++] = 0;
+        }
+        fill = (fill + (rem ? 1u : 0u) + 3u) & ~3u;
+        wave_sync();
+        const uint32_t tail_idx = (uint32_t)(((stuffed_bytes * 8 + rem) >> 5) - p.out_word_base - wbase);  // word holding the residual
+        const uint32_t tail_raw = (tail_idx * 4 < fill) ? reinterpret_cast<const uint32_t*>(stage)[tail_idx] : 0u;
+        flush(true);
+        if (lane == 0) {
+            const uint64_t sbits_total = stuffed_bytes * 8 + rem;
+            jpegenc_result r;
+            r.n_full_words = sbits_total >> 5;
+            r.total_bits_unstuffed = total_bits;
+            r.total_bytes_stuffed = stuffed_bytes;
+            r.tail_bits = (uint8_t)(sbits_total & 31u);
+            r.eof_partial_ready = r.tail_bits ? 1 : 0;
+            r.tail_word = r.tail_bits ? __builtin_bswap32(tail_raw) : 0u;
+            const uint64_t need = r.n_full_words + (r.tail_bits ? 1 : 0) - p.out_word_base;
+            r.status = (need > p.cap_words) ? (int16_t)JPEGENC_E_TOO_SMALL : (int16_t)JPEGENC_OK;
+            p.results[img] = r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Hand-off words of the single-launch form: one 64-bit word per chunk and chain, tag << 32 | payload, written
+// once by an 8-byte device-scope store and polled by 8-byte device-scope loads (the word is the whole message:
+// no other memory has to be ordered with it).  Payload bit 31 = some chunk up to here gave up waiting.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void publish_state(uint64_t* st, uint32_t tag, uint32_t payload, int lane) {
+    if (lane == 0) __hip_atomic_store(st, ((uint64_t)tag << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct Gathered {
+    uint64_t sum;   // of the payloads' field over the c words
+    uint32_t last;  // payload of word c - 1
+    uint32_t err;   // 0x80000000 if a payload carried the error bit or the wait ran out
+};
+// Waits for st[0 .. c) to carry `tag` (512 words at a time, eight per lane, all requested together: the
+// chunks of a launch finish at about the same time, so one round trip usually finds them all) and sums `field`
+// of their payloads.  The wait is bounded: a chunk whose predecessors do not arrive within about a tenth of a
+// second goes on with what it has and raises the error bit, which travels down the chain into the image's result.
+__device__ __forceinline__ Gathered gather_states(const uint64_t* st, uint32_t c, uint32_t tag, uint32_t field, int lane,
+                                                  bool error_bit = true) {
+    Gathered g{0, 0, 0};
+    for (uint32_t j0 = 0; j0 < c; j0 += 512) {
+        uint64_t v[8];
+        for (uint32_t spins = 0;; ++spins) {
+            bool ready = true;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t j = j0 + 64u * u + (uint32_t)lane;
+                v[u] = (j < c) ? __hip_atomic_load(st + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((uint64_t)tag << 32);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ready = ready && (uint32_t)(v[u] >> 32) == tag;
+            if (__all((int)ready)) break;
+            if (g.err || spins >= (1u << 16)) {  // (after one wait has run out no further one is tried)
+                g.err = 0x80000000u;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        uint32_t part = 0, any_err = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t pay = ((uint32_t)(v[u] >> 32) == tag) ? (uint32_t)v[u] : 0u;
+            part += pay & field;  // (eight fields of at most 31 bits: the bit counts are 19 bits, the 0xFF counts 16)
+            any_err |= pay;
+            const uint32_t jl = c - 1u - j0;  // where word c - 1 sits in this round, if it does
+            if (jl < 512u && (jl >> 6) == (uint32_t)u) g.last = readlane_u32(pay, (int)(jl & 63u));
+        }
+        if (error_bit && __any((int)(any_err >> 31))) g.err = 0x80000000u;  // (error_bit false: payloads of 32 data bits)
+        g.sum += (uint64_t)readlane_u32(wave_incl_scan_dpp(part), 63);
+    }
+    return g;
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_encode_chunks
 // ------------------------------------------------------------------------------------------------
 // LDS budget: 64 regions of REGION words plus the Huffman table.  REGION = 41 lets twelve workgroups (three
@@ -519,7 +883,7 @@ __device__ __forceinline__ uint32_t fit_range_end(uint32_t need_incl, uint32_t l
     return lo + (uint32_t)__popcll(fits);
 }
 
-template <int ALIGN, bool QUANT, bool WRAP, int REGION>
+template <int ALIGN, bool QUANT, bool WRAP, int REGION, bool FUSED>
 __global__ __launch_bounds__(64, REGION > kRegionSmall ? 2 : 3) void k_encode_chunks(EncodeParams p) {
     constexpr int kRegionWords = REGION;
     constexpr int kOwnWords = kRegionWords - 1;  // first pass: REGION - 2 usable words and one zero word behind them
@@ -530,8 +894,12 @@ __global__ __launch_bounds__(64, REGION > kRegionSmall ? 2 : 3) void k_encode_ch
     constexpr uint32_t kFitWords = 64 * kRegionWords;  // what the exact regions of one pass may add up to
     static_assert(kFitWords >= 16 * (kMaxMcuWords + 2), "a pass holds at least 16 worst-case MCUs");
     __shared__ __attribute__((aligned(16))) uint32_t priv[kPrivWords];
-    __shared__ uint32_t htab[kHtabEntries];  // code << size
-    __shared__ uint8_t hlen[kHtabEntries];   // code length + size
+    // the Huffman table: code << size as words, then code length + size as bytes (one array: the single-launch
+    // form reuses it as the stage of the stuffing step)
+    __shared__ __attribute__((aligned(16))) uint32_t tables[kHtabEntries + kHtabEntries / 4];
+    uint32_t* const htab = tables;
+    uint8_t* const hlen = reinterpret_cast<uint8_t*>(tables + kHtabEntries);
+    static_assert(!FUSED || sizeof(tables) >= kStageBytes, "the stage fits the table's place");
     const int lane = threadIdx.x;
     // grid: x = chunk of the image, y and z = image (no division)
     const uint32_t c = blockIdx.x;
@@ -605,6 +973,7 @@ __global__ __launch_bounds__(64, REGION > kRegionSmall ? 2 : 3) void k_encode_ch
     uint32_t chunk_total = 0;  // bits written to the slot so far
     uint32_t carry = 0;        // partial last word of the slot (left-aligned), when chunk_total % 32 != 0
     uint32_t tail8 = 0;        // last 8 bits of the stream so far (uniform)
+    uint32_t tail32 = 0;       // FUSED: its last 32 bits
 
     // Pass loop.  The first pass codes all 64 lanes at once, every lane into its own region (see kRegionWords).
     // It counts every lane's bits even when a lane cannot store them, so if any lane overflowed its region
@@ -797,25 +1166,38 @@ __global__ __launch_bounds__(64, REGION > kRegionSmall ? 2 : 3) void k_encode_ch
             const uint32_t nw = (gtotal + 31u) >> 5;
             const uint32_t nd = (s + gtotal + 31u) >> 5;
             // The chunk's first pass starts the slot: whole groups of four words go out as they are, four per
-            // lane and step; the general loop below is left with the last 0 to 3 words.
+            // lane and step; the general loop below is left with the last 0 to 3 words.  (Single-launch form:
+            // a chunk done in its first pass stays in the LDS, where the stuffing step below reads it.)
             uint32_t t_first = lane;
-            if (!QUANT && chunk_total == 0) {
+            const bool to_slot = !FUSED || fit;
+            if (!QUANT && chunk_total == 0 && to_slot) {
                 const uint32_t nq = nd >> 2;
-                for (uint32_t q = lane; q < nq; q += 64)
-                    __builtin_nontemporal_store(reinterpret_cast<const u32x4*>(priv)[q], reinterpret_cast<u32x4*>(slot) + q);
+                for (uint32_t q = lane; q < nq; q += 64) {
+                    if constexpr (FUSED)  // read back by this wave in a moment: kept in the L2
+                        reinterpret_cast<u32x4*>(slot)[q] = reinterpret_cast<const u32x4*>(priv)[q];
+                    else
+                        __builtin_nontemporal_store(reinterpret_cast<const u32x4*>(priv)[q], reinterpret_cast<u32x4*>(slot) + q);
+                }
                 t_first = 4u * nq + lane;
             }
-            for (uint32_t t = t_first; t < nd; t += 64) {
+            for (uint32_t t = t_first; to_slot && t < nd; t += 64) {
                 const uint32_t wlo = (t < nw) ? priv[t] : 0u;
                 const uint32_t whi = (t >= 1 && t - 1 < nw) ? priv[t - 1] : 0u;
                 uint32_t w = __builtin_amdgcn_alignbit(whi, wlo, s);
                 if (t == 0) w |= carry;
-                __builtin_nontemporal_store(w, &slot[d0 + t]);  // streamed: keeps the pixels in L2 for the next component
+                if constexpr (FUSED)
+                    slot[d0 + t] = w;
+                else
+                    __builtin_nontemporal_store(w, &slot[d0 + t]);  // streamed: keeps the pixels in L2 for the next component
             }
             const uint32_t nt = chunk_total + gtotal;
             {   // the last 8 bits of the stream so far (a non-empty pass has at least 18 bits)
                 const uint32_t l = gtotal - 8u, wi = l >> 5, sh = l & 31u;
                 tail8 = (sh ? ((priv[wi] << sh) | (priv[wi + 1] >> (32u - sh))) : priv[wi]) >> 24;
+            }
+            if (FUSED && gtotal >= 32u) {  // (a chunk that another one follows holds 64 MCUs: at least 1152 bits)
+                const uint32_t l = gtotal - 32u, wi = l >> 5, sh = l & 31u;
+                tail32 = sh ? ((priv[wi] << sh) | (priv[wi + 1] >> (32u - sh))) : priv[wi];
             }
             if (nt & 31u) {  // keep the partial last word for the next pass (uniform)
                 const uint32_t t = nd - 1;
@@ -835,7 +1217,65 @@ __global__ __launch_bounds__(64, REGION > kRegionSmall ? 2 : 3) void k_encode_ch
         hi = fit_range_end(need_before + need, lo, readlane_u32(need_before, (int)lo), kFitWords);
     }
     // bit count (at most 64 * 4980 < 2^24) and, for the successor's first byte, the stream's last 8 bits
-    if (lane == 0) p.chunk_bits[gid] = chunk_total | (tail8 << 24);
+    if (!FUSED && lane == 0) p.chunk_bits[gid] = chunk_total | (tail8 << 24);
+
+    if constexpr (FUSED) {
+        // ---- single-launch form: place, stuff and write this chunk's stream ----------------------------
+        // Two chains of hand-off words run through the image's chunks: bit counts (with the stream's last 8
+        // bits), then 0xFF counts, which need the bit offsets; a third word per chunk carries its last 32 bits,
+        // which the image's last chunk may need for a tail word it shares with the chunk before it.  Nothing
+        // else crosses between waves, so no fences.  Every chunk of the launch is resident (the host's limit),
+        // so every word a chunk waits for is on its way.
+        const uint32_t n_chunks = p.n_images * p.cpi;
+        uint64_t* const st_bits = p.state + (uint64_t)img * p.cpi;
+        uint64_t* const st_ff = st_bits + n_chunks;
+        uint64_t* const st_tail = st_ff + n_chunks;
+        // the chunk's stream: still in the LDS from word 0 on when the first pass sufficed, else in its slot
+        const uint32_t* const stream = fit ? slot : priv;
+        if (fit) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the slot is written: this wave reads it back below
+        if (c + 2 == p.cpi) publish_state(st_tail + c, p.generation, tail32, lane);
+        publish_state(st_bits + c, p.generation, chunk_total | (tail8 << 23), lane);
+        const Gathered gb = gather_states(st_bits, c, p.generation, 0x7FFFFu, lane);
+        const uint64_t o = gb.sum;
+        const uint32_t pred8 = c ? ((gb.last >> 23) & 0xFFu) : 0u;
+        StuffParams sp;
+        sp.slots = p.slots;
+        sp.chunk_bits = p.chunk_bits;
+        sp.bit_off = nullptr;
+        sp.chunk_ff = nullptr;
+        sp.ff_off = nullptr;
+        sp.words_out = p.words_out;
+        sp.out_stride = p.out_stride;
+        sp.cap_words = p.cap_words;
+        sp.results = p.results;
+        sp.cpi = p.cpi;
+        sp.pred_tail8 = 0;
+        sp.bit_base = sp.ff_base = sp.out_word_base = 0;
+        sp.eof = 1;
+        sp.spec_depth = kStuffDepth;
+        sp.inline_scan = 0;
+        uint4 w[kStuffDepth];
+        uint32_t w4[kStuffDepth];
+        request_chunk<kStuffDepth>(stream, lane, w, w4);
+        const bool one_pass = chunk_total <= 8u * 1024u * kStuffDepth - 64u;
+        const uint32_t mine = count_owned_ff<kStuffDepth>(stream, w, w4, chunk_total, o, pred8, lane);
+        publish_state(st_ff + c, p.generation, mine | gb.err, lane);
+        const Gathered gf = gather_states(st_ff, c, p.generation, 0x7FFFFFFFu, lane);
+        const bool last = c + 1 == p.cpi;
+        uint32_t prev_tail32 = 0, tail_err = 0;
+        if (last && c > 0) {
+            const Gathered gt = gather_states(st_tail + (c - 1), 1u, p.generation, 0u, lane, false);
+            prev_tail32 = gt.last;
+            tail_err = gt.err;
+        }
+        wave_sync();  // the Huffman table has served: its place is this wave's stage
+        write_chunk<kStuffDepth>(sp, stream, w, w4, one_pass, reinterpret_cast<uint8_t*>(tables), img, c, gid, chunk_total, o,
+                                 gf.sum, pred8, lane, true, c ? (gb.last & 0x7FFFFu) : 0u, prev_tail32);
+        if (last && (gb.err | gf.err | tail_err) && lane == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            p.results[img].status = (int16_t)JPEGENC_E_HIP;  // a wait ran out: the words are not to be trusted
+        }
+    }
 }
 
 #ifndef JPEGENC_TU_QUANT  // (the second translation unit holds the quantising encode variants only)
@@ -843,7 +1283,6 @@ __global__ __launch_bounds__(64, REGION > kRegionSmall ? 2 : 3) void k_encode_ch
 // ------------------------------------------------------------------------------------------------
 // k_scan: exclusive prefix per image, one 256-thread workgroup per image.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t kCountMask = 0xFFFFFFu;  // counts live in the low 24 bits of their words
 
 __global__ __launch_bounds__(256) void k_scan(ScanParams p) {
     __shared__ uint64_t part[256];
@@ -878,18 +1317,6 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams p) {
 // after them (ff_checker.sv:96-179).  Output byte i of the stuffed stream lives in word i/4 at bits
 // 31-8*(i%4), i.e. at byte address i^3 of a little-endian word array.
 // ------------------------------------------------------------------------------------------------
-constexpr int kStageBytes = 2048 + 64;  // one step: <= 1024 bytes, doubled by stuffing, + residual
-
-constexpr int kStuffWaves = 4;  // independent waves per workgroup, one chunk each
-constexpr int kStuffDepth = 5;  // steps whose loads are in flight together
-
-// bit 7 of every byte of the result is set iff that byte of v is 0xFF: the low seven bits plus one carry
-// into bit 7 exactly when they are all ones, and never beyond the byte
-__device__ __forceinline__ uint32_t ff_flags(uint32_t v) {
-    const uint32_t t = (v & 0x7F7F7F7Fu) + 0x01010101u;
-    return t & v & 0x80808080u;
-}
-
 // ------------------------------------------------------------------------------------------------
 // k_stuff_count: number of 0xFF bytes each chunk owns (ownership rule above).  One wave
 // per chunk, 16 stream bytes per lane and step.  The byte that begins in the predecessor is taken on
@@ -902,71 +1329,6 @@ __device__ __forceinline__ uint32_t wave_sum_before(const uint32_t* counts, uint
     uint32_t s = 0;
     for (uint32_t j = lane; j < c; j += 64) s += counts[j] & kCountMask;
     return readlane_u32(wave_incl_scan_dpp(s), 63);
-}
-
-// Requests the first SPEC 1 KB steps of a chunk stream: 16 bytes per lane and step plus the word behind them.
-template <int SPEC>
-__device__ __forceinline__ void request_chunk(const uint32_t* S, int lane, uint4 (&w)[kStuffDepth], uint32_t (&w4)[kStuffDepth]) {
-#pragma unroll
-    for (int u = 0; u < kStuffDepth; ++u) {
-        if (u < SPEC) {
-            const uint32_t* q = S + 256 * u + 4 * lane;
-            w[u] = *reinterpret_cast<const uint4*>(q);
-            w4[u] = q[4];
-        }
-    }
-}
-
-// The 0xFF bytes owned by the chunk whose stream S (n bits) starts at bit o of the image's stream; pred8 = the
-// last 8 bits before it.  w, w4: the first SPEC steps as requested by request_chunk (left untouched when the
-// chunk has no more than kStuffDepth steps).  The same value in every lane.
-template <int SPEC>
-__device__ __forceinline__ uint32_t count_owned_ff(const uint32_t* S, uint4 (&w)[kStuffDepth], uint32_t (&w4)[kStuffDepth],
-                                                   uint32_t n, uint64_t o, uint32_t pred8, int lane) {
-    const uint32_t sbits = (uint32_t)(o & 7u);  // bits of the first owned byte that lie in the predecessor
-    const uint32_t A = (8u - sbits) & 7u;
-    const uint32_t nbytes = (uint32_t)(((o + n) >> 3) - (o >> 3));
-    const uint32_t nm = nbytes - (sbits ? 1u : 0u);  // owned bytes that lie entirely in this chunk
-    uint32_t total = 0;
-    if (sbits != 0 && lane == 0) {
-        const uint32_t pw = pred8;
-        const uint32_t sb = ((pw << A) | (readlane_u32(w[0].x, 0) >> (32u - A))) & 0xFFu;
-        total = (sb == 0xFFu) ? 1u : 0u;
-    }
-    for (uint32_t pass = 0; pass < nm; pass += 1024 * kStuffDepth) {
-#pragma unroll
-        for (int u = 0; u < kStuffDepth; ++u) {  // what was not requested ahead
-            const uint32_t* q = S + ((pass >> 2) + 256 * u) + 4 * lane;
-            if ((pass != 0 || u >= SPEC) && pass + 1024u * u < nm) {  // uniform
-                w[u] = *reinterpret_cast<const uint4*>(q);
-                w4[u] = q[4];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < kStuffDepth; ++u) {
-            const uint32_t base = pass + 1024u * u;
-            if (base < nm) {  // uniform
-                uint32_t v0 = w[u].x, v1 = w[u].y, v2 = w[u].z, v3 = w[u].w;
-                if (A != 0) {  // uniform
-                    v0 = __builtin_amdgcn_alignbit(w[u].x, w[u].y, 32u - A);
-                    v1 = __builtin_amdgcn_alignbit(w[u].y, w[u].z, 32u - A);
-                    v2 = __builtin_amdgcn_alignbit(w[u].z, w[u].w, 32u - A);
-                    v3 = __builtin_amdgcn_alignbit(w[u].w, w4[u], 32u - A);
-                }
-                uint32_t m0 = ff_flags(v0), m1 = ff_flags(v1), m2 = ff_flags(v2), m3 = ff_flags(v3);
-                if (base + 1024 > nm) {  // uniform: the last step, some bytes lie behind the chunk's last whole byte
-                    const uint32_t j = base + 16u * (uint32_t)lane;
-                    const int nv = (j < nm) ? (int)min(16u, nm - j) : 0;
-                    auto keep = [&](int nb) { return nb >= 4 ? 0xFFFFFFFFu : nb <= 0 ? 0u : ~(0xFFFFFFFFu >> (8 * nb)); };
-                    m0 &= keep(nv); m1 &= keep(nv - 4); m2 &= keep(nv - 8); m3 &= keep(nv - 12);
-                }
-                total += __popc(m0) + __popc(m1) + __popc(m2) + __popc(m3);
-            }
-        }
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d);
-    return total;
 }
 
 template <int SPEC>  // 1 KB steps requested before the chunk's length is known
@@ -1004,226 +1366,6 @@ __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_count(StuffParams p,
 // (one per wave) and leave it as whole words; the bytes of a word shared with a neighbouring chunk are
 // stored one by one.
 // ------------------------------------------------------------------------------------------------
-// Writes the stuffed bytes of one chunk (stream S of n bits at bit o of the image's stream, ff_before 0xFF bytes
-// owned by the chunks before it, pred8 = the last 8 bits before it) and, for the image's last chunk at end of
-// file, the result record.  w, w4: the first SPEC steps as requested by request_chunk when have_first (uniform),
-// else they are requested here.  `stage`: this wave's kStageBytes of LDS.
-template <int SPEC>
-__device__ __forceinline__ void write_chunk(const StuffParams& p, const uint32_t* S, uint4 (&w)[kStuffDepth],
-                                            uint32_t (&w4)[kStuffDepth], bool have_first, uint8_t* const stage, uint32_t img,
-                                            uint32_t c, uint32_t gid, uint32_t n, uint64_t o, uint64_t ff_before,
-                                            uint32_t pred8, int lane) {
-    if (!have_first) request_chunk<SPEC>(S, lane, w, w4);  // (uniform)
-    const uint64_t q_first = o >> 3;
-    const uint32_t sbits = (uint32_t)(o & 7u);
-    const uint32_t A = (8u - sbits) & 7u;
-    const uint32_t nbytes = (uint32_t)(((o + n) >> 3) - q_first);
-    const uint32_t nm = nbytes - (sbits ? 1u : 0u);
-
-    uint32_t* const out_words = p.words_out + (uint64_t)img * p.out_stride;
-    uint8_t* const out_bytes = reinterpret_cast<uint8_t*>(out_words);
-    const uint64_t cap_bytes = p.cap_words * 4;
-    const uint64_t pos0 = q_first + ff_before + p.ff_base;  // stuffed byte offset of the first owned byte
-    uint64_t wbase = (pos0 >> 2) - p.out_word_base;             // index in out_words of stage[0]
-    uint32_t head = (uint32_t)(pos0 & 3u);          // leading bytes of the stage's first word that belong to the previous chunk
-    uint32_t fill = head;                           // bytes in the stage (uniform)
-
-    if (sbits != 0) {  // the byte that begins in the predecessor: its last 8 bits travel with its bit count
-        const uint32_t pw = pred8;
-        const uint32_t sb = ((pw << A) | (readlane_u32(w[0].x, 0) >> (32u - A))) & 0xFFu;
-        if (lane == 0) {
-            stage[fill] = (uint8_t)sb;
-            stage[fill + 1] = 0;
-        }
-        fill += (sb == 0xFFu) ? 2u : 1u;
-    }
-
-    auto flush = [&](bool final_pad) {
-        // stores the complete words of the stage, four per lane and turn; keeps the residual bytes for
-        // the next step
-        const uint32_t nwords = final_pad ? ((fill + 3u) >> 2) : (fill >> 2);
-        for (uint32_t i = 4u * lane; i < nwords; i += 256) {
-            const uint4 raw = *reinterpret_cast<const uint4*>(stage + 4 * i);
-            const uint64_t gw = wbase + i;
-            const uint32_t t[4] = {__builtin_bswap32(raw.x), __builtin_bswap32(raw.y), __builtin_bswap32(raw.z),
-                                   __builtin_bswap32(raw.w)};
-            if (i + 4 <= nwords && gw + 4 <= p.cap_words && !(i == 0 && head)) {
-                __builtin_memcpy(out_words + gw, t, 16);  // word-aligned 16-byte store
-            } else {
-#pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) {
-                    if (i + k >= nwords) break;
-                    if (i + k == 0 && head) {  // word shared with the previous chunk: only our bytes
-                        for (uint32_t b = head; b < 4; ++b) {
-                            const uint64_t ga = gw * 4 + b;
-                            if (ga < cap_bytes) out_bytes[ga ^ 3] = stage[b];
-                        }
-                    } else if (gw + k < p.cap_words) {
-                        out_words[gw + k] = t[k];
-                    }
-                }
-            }
-        }
-        wave_sync();
-        if (nwords) {
-            const uint32_t rest = final_pad ? 0u : (fill & 3u);
-            if (lane < rest) stage[lane] = stage[nwords * 4 + lane];  // reads and writes are disjoint words
-            wbase += nwords;
-            fill = rest;
-            head = 0;
-        }
-        wave_sync();
-    };
-
-    // One word holding at least one 0xFF (flags m), all four bytes valid, to stage offset `at`.  Every byte
-    // goes out as the pair (byte, 0x00): the zero is the stuffing when the byte is 0xFF and is
-    // overwritten by the next byte's pair otherwise.  The last byte of a lane's last word must not
-    // write beyond the lane's bytes: it is stored alone unless it is 0xFF.
-    auto ff_word = [&](uint32_t at, uint32_t v, uint32_t m, bool lane_end) {
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const uint16_t pair = (uint16_t)((v >> (24 - 8 * b)) & 0xFFu);
-            const uint32_t f = (m >> (31 - 8 * b)) & 1u;
-            if (b < 3 || !lane_end || f)
-                __builtin_memcpy(&stage[at], &pair, 2);
-            else
-                stage[at] = (uint8_t)pair;
-            at += 1u + f;
-        }
-    };
-
-    for (uint32_t pass = 0; pass < nm; pass += 1024 * kStuffDepth) {
-#pragma unroll
-        for (int u = 0; u < kStuffDepth; ++u) {  // what was not requested ahead
-            const uint32_t* q = S + ((pass >> 2) + 256 * u) + 4 * lane;
-            if ((pass != 0 || u >= SPEC) && pass + 1024u * u < nm) {  // uniform
-                w[u] = *reinterpret_cast<const uint4*>(q);
-                w4[u] = q[4];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < kStuffDepth; ++u) {
-            const uint32_t base = pass + 1024u * u;
-            if (base >= nm) break;  // uniform
-            const uint32_t j = base + 16u * (uint32_t)lane;
-            const int nvalid = (j < nm) ? (int)min(16u, nm - j) : 0;
-            uint32_t v[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
-            if (A != 0) {  // uniform
-                v[0] = __builtin_amdgcn_alignbit(w[u].x, w[u].y, 32u - A);
-                v[1] = __builtin_amdgcn_alignbit(w[u].y, w[u].z, 32u - A);
-                v[2] = __builtin_amdgcn_alignbit(w[u].z, w[u].w, 32u - A);
-                v[3] = __builtin_amdgcn_alignbit(w[u].w, w4[u], 32u - A);
-            }
-            uint32_t m[4] = {ff_flags(v[0]), ff_flags(v[1]), ff_flags(v[2]), ff_flags(v[3])};
-            const bool partial = base + 1024 > nm;  // uniform: the chunk's last step, some lanes hold fewer than 16 bytes
-            if (partial) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int nb = nvalid - 4 * i;  // valid bytes of word i
-                    m[i] &= nb >= 4 ? 0xFFFFFFFFu : nb <= 0 ? 0u : ~(0xFFFFFFFFu >> (8 * nb));
-                }
-            }
-            const uint32_t cnt = __popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]);
-            const uint32_t incl = wave_incl_scan_dpp(cnt);
-            const uint32_t it_ff = readlane_u32(incl, 63);
-            uint32_t a = fill + 16u * (uint32_t)lane + (incl - cnt);  // stage offset of this lane's first byte
-            if (nvalid == 16 && cnt == 0) {
-                uint32_t t[4] = {__builtin_bswap32(v[0]), __builtin_bswap32(v[1]), __builtin_bswap32(v[2]),
-                                 __builtin_bswap32(v[3])};
-                __builtin_memcpy(&stage[a], t, 16);  // byte-aligned 16-byte store
-            } else if (nvalid == 16) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (m[i] == 0) {
-                        const uint32_t t = __builtin_bswap32(v[i]);
-                        __builtin_memcpy(&stage[a], &t, 4);
-                    } else {
-                        ff_word(a, v[i], m[i], i == 3);
-                    }
-                    a += 4u + __popc(m[i]);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int nb = nvalid - 4 * i;
-                    for (int b = 0; b < 4 && b < nb; ++b) {
-                        stage[a++] = (uint8_t)(v[i] >> (24 - 8 * b));
-                        if (m[i] & (0x80000000u >> (8 * b))) stage[a++] = 0;
-                    }
-                }
-            }
-            fill += min(1024u, nm - base) + it_ff;
-            wave_sync();
-            flush(false);
-        }
-    }
-
-    const bool last = (c == p.cpi - 1) && p.eof;
-    if (!last) {
-        // bytes after the last whole word belong to a word shared with the next chunk
-        if ((uint32_t)lane >= head && (uint32_t)lane < fill) {
-            const uint64_t ga = wbase * 4 + lane;
-            if (ga < cap_bytes) out_bytes[ga ^ 3] = stage[lane];
-        }
-    } else {
-        // end of file: the incomplete last byte is never stuffed; the residual bits are presented
-        // left-aligned in one more word with their count (ff_checker.sv:289-360, functional)
-        const uint64_t total_bits = o + n;
-        const uint32_t rem = (uint32_t)(total_bits & 7u);
-        const uint64_t stuffed_bytes = (wbase + p.out_word_base) * 4 + fill;
-        if (lane == 0) {
-            if (head != 0 && c > 0) {
-                // Nothing has left the stage yet and its first word is shared with the previous chunk, so
-                // the word reported as tail_word may be that one: fetch the previous chunk's last `head`
-                // stuffed bytes (its last three owned bytes with their stuffing suffice) into the stage.
-                // They are only read here; in memory that chunk writes them itself.
-                const uint32_t np = p.chunk_bits[gid - 1] & kCountMask;
-                const uint32_t* Sp = S - kSlotWords;
-                const uint32_t l = np - sbits - 24u, wi = l >> 5, sh = l & 31u;
-                const uint32_t w32 = sh ? __builtin_amdgcn_alignbit(Sp[wi], Sp[wi + 1], 32u - sh) : Sp[wi];
-                uint32_t seq = 0;  // the last stuffed bytes, newest in the low byte
-                for (int k = 2; k >= 0; --k) {
-                    const uint32_t b = (w32 >> (8 + 8 * k)) & 0xFFu;
-                    seq = (seq << 8) | b;
-                    if (b == 0xFFu) seq <<= 8;
-                }
-                for (uint32_t k = 0; k < head; ++k) stage[k] = (uint8_t)(seq >> (8 * (head - 1 - k)));
-            } else if (head != 0) {
-                // a one-chunk segment whose first word begins in the segment before it: those bytes are the
-                // neighbour's and read as zero here, like the ones it leaves zero in memory
-                for (uint32_t k = 0; k < head; ++k) stage[k] = 0;
-            }
-            uint32_t f = fill;
-            if (rem) {
-                // the last rem bits of the chunk stream, left-aligned in a byte
-                const uint32_t l = n - rem, wi = l >> 5, sh = l & 31u;
-                const uint32_t w32 = sh ? __builtin_amdgcn_alignbit(S[wi], S[wi + 1], 32u - sh) : S[wi];
-                const uint32_t vb = w32 >> 24;
-                stage[f++] = (uint8_t)(vb & (0xFFu << (8u - rem)));
-            }
-            while (f & 3u) stage[f++] = 0;
-        }
-        fill = (fill + (rem ? 1u : 0u) + 3u) & ~3u;
-        wave_sync();
-        const uint32_t tail_idx = (uint32_t)(((stuffed_bytes * 8 + rem) >> 5) - p.out_word_base - wbase);  // word holding the residual
-        const uint32_t tail_raw = (tail_idx * 4 < fill) ? reinterpret_cast<const uint32_t*>(stage)[tail_idx] : 0u;
-        flush(true);
-        if (lane == 0) {
-            const uint64_t sbits_total = stuffed_bytes * 8 + rem;
-            jpegenc_result r;
-            r.n_full_words = sbits_total >> 5;
-            r.total_bits_unstuffed = total_bits;
-            r.total_bytes_stuffed = stuffed_bytes;
-            r.tail_bits = (uint8_t)(sbits_total & 31u);
-            r.eof_partial_ready = r.tail_bits ? 1 : 0;
-            r.tail_word = r.tail_bits ? __builtin_bswap32(tail_raw) : 0u;
-            const uint64_t need = r.n_full_words + (r.tail_bits ? 1 : 0) - p.out_word_base;
-            r.status = (need > p.cap_words) ? (int16_t)JPEGENC_E_TOO_SMALL : (int16_t)JPEGENC_OK;
-            p.results[img] = r;
-        }
-    }
-}
-
 template <int SPEC>
 __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_write(StuffParams p, uint32_t n_chunks) {
     __shared__ __attribute__((aligned(16))) uint8_t stage_all[kStuffWaves][kStageBytes];
@@ -1347,12 +1489,12 @@ hipError_t static_workspace(void** ptr) {
 // This file is compiled twice.  The variants of k_encode_chunks with a quantiser are built in a translation
 // unit of their own (-DJPEGENC_TU_QUANT) with the scheduler's max-ILP strategy: there it removes their spills
 // (9 % faster), while the variants for the all-ones tables lose 5 % under it and keep the default strategy.
-template <int ALIGN, bool QUANT, int REGION>
+template <int ALIGN, bool QUANT, int REGION, bool FUSED = false>
 static hipError_t launch_encode_b(const EncodeParams& p, dim3 grid, hipStream_t s) {
     if (p.flags & 1u)
-        hipLaunchKernelGGL((k_encode_chunks<ALIGN, QUANT, true, REGION>), grid, dim3(64), 0, s, p);
+        hipLaunchKernelGGL((k_encode_chunks<ALIGN, QUANT, true, REGION, FUSED>), grid, dim3(64), 0, s, p);
     else
-        hipLaunchKernelGGL((k_encode_chunks<ALIGN, QUANT, false, REGION>), grid, dim3(64), 0, s, p);
+        hipLaunchKernelGGL((k_encode_chunks<ALIGN, QUANT, false, REGION, FUSED>), grid, dim3(64), 0, s, p);
     return hipGetLastError();
 }
 
@@ -1375,6 +1517,12 @@ hipError_t launch_encode(const EncodeParams& p_in, uint32_t n_images, int align,
     const uint32_t nz = (n_images + 65534u) / 65535u;
     if (nz > 65535u) return hipErrorInvalidValue;
     const dim3 grid(p.cpi, ny, nz);
+    if (p.state) {
+        // single-launch form: only the common variant, with large regions (a launch this small leaves most of
+        // the LDS unused anyway)
+        if (p.qmul || align < 8 || chunks > kSingleLaunchMaxChunks) return hipErrorInvalidValue;
+        return launch_encode_b<8, false, kRegionLarge, true>(p, grid, s);
+    }
     if (p.qmul) return launch_encode_quant(p, grid, align, s);
     // large regions exist for the common variant only (8-byte-aligned rows, all-ones tables: quantised streams are short)
     if (align >= 8) return p.large_regions ? launch_encode_b<8, false, kRegionLarge>(p, grid, s) : launch_encode_b<8, false, kRegionSmall>(p, grid, s);

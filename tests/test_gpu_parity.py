@@ -13,10 +13,14 @@ from conftest import load_pkg, natural_like
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def enc():
+@pytest.fixture(scope="module", params=["auto", "split"])
+def enc(request):
+    """Small calls run as one kernel launch by default and as separate kernels on request: both forms take every
+    test that uses this encoder."""
     pkg = load_pkg()
     e = pkg.JpegTop()
+    if request.param == "split":
+        e.set_pipeline(e.PIPELINE_SPLIT)
     yield e
     e.close()
 

@@ -1,15 +1,14 @@
 #!/bin/bash
-# Small launches (1 to 64 frames) on two builds, ab/base.so and ab/new.so (run inside gpurun): ms per step.
-# Leaves ab/new.so installed.
-for f in 1 4 16 32 64; do
-  for v in base new; do
-    cp ab/$v.so jpeg-encoder_amd/libjpegenc.so
-    timeout -k 10 200 python -u bench.py --frames $f --steps 50 --warmup 5 --no-cpu --no-profile > gpurun_out/lat_$v.log 2>&1 || { tail -5 gpurun_out/lat_$v.log; exit 1; }
-    python - <<PY
-import json
-l=[x for x in open("gpurun_out/lat_$v.log") if x.startswith("{")][-1]
-d=json.loads(l)
-print("frames", $f, "$v", "us/step", round(1000*d["ms_per_step"],1), "Mpx/s", d["value"])
+# Small calls (1 to 64 frames of 1080p) without event recording, as one kernel launch (default) and as separate
+# kernels (--split); run inside gpurun.  us per call and Mpixel/s.
+for f in 1 2 4 8 16; do
+  for v in "" "--split"; do
+    timeout -k 10 200 python -u bench.py --frames $f --steps 200 --warmup 20 --no-cpu --no-profile $v $LAT_ARGS > gpurun_out/lat.log 2>&1 || { tail -5 gpurun_out/lat.log; exit 1; }
+    python - "$f" "$v" <<'PY'
+import json, sys
+l = [x for x in open("gpurun_out/lat.log") if x.startswith("{")][-1]
+d = json.loads(l)
+print("frames %3s %-8s %8.1f us/call %9.0f Mpx/s" % (sys.argv[1], sys.argv[2] or "single", 1000 * d["ms_per_step"], d["value"]))
 PY
   done
 done
