@@ -380,6 +380,22 @@ def bench_16k(args, pkg, torch, dist, dev, world, rank, backend):
                 good = good and np.array_equal(got, want) and int(table[0, 3]) == r.tail_word
                 extra["cpu_baseline"] = {"value": round(rows * n / (time.perf_counter() - t0) / 1e6, 2), "unit": "Mpixel/s",
                                          "cores": 1, "kind": "port", "sample": "stripe 0 (%d x %d), compared word for word" % (n, rows)}
+        if not args.no_cpu and args.mode == "mono16k" and n <= 8192:
+            # the merged stream against the same image coded in one call on this GPU (bit-exact against the oracle
+            # in tests/): every word and the end-of-file fields
+            whole = torch.cat([stripe_pixels(s) for s in range(stripes)])
+            cap = n * n * 3 // 4
+            d_words = torch.zeros(cap, dtype=torch.int32, device=dev)
+            d_res = torch.zeros(32, dtype=torch.uint8, device=dev)
+            enc.encode_batch_device(whole.data_ptr(), 1, n, n, n * 3, n * n * 3, d_words.data_ptr(), cap, d_res.data_ptr())
+            enc.synchronize()
+            one = d_res.cpu().numpy().view(pkg.RESULT_DTYPE)[0]
+            k = int(one["n_full_words"]) + (1 if one["tail_bits"] else 0)
+            same = (int(one["status"]) == 0 and k <= wds.numel() and torch.equal(wds[:k].to(dev), d_words[:k])
+                    and not bool(wds[k:].any())
+                    and all(int(res[f]) == int(one[f]) for f in ("n_full_words", "tail_bits", "tail_word", "total_bytes_stuffed")))
+            good = good and same
+            extra["same_as_one_call"] = bool(same)
         rc = 0 if good else 1
         line = {"metric": "encoded Mpixel/s (one %dx%d image, %s)" % (n, n, args.mode), "value": round(n * n * args.steps / elapsed / 1e6, 1),
                 "unit": "Mpixel/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

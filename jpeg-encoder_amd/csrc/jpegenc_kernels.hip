@@ -1462,6 +1462,7 @@ hipError_t launch_pad_edges(const uint8_t* src, int64_t stride, int64_t image_st
     const int w8 = (w + 7) & ~7, h8 = (h + 7) & ~7;
     const int64_t px = (int64_t)w8 * h8;
     if ((px + 255) / 256 > 0x7FFFFFFFll) return hipErrorInvalidValue;
+    (void)hipGetLastError();
     for (int first = 0; first < n_images; first += 65535) {  // the grid's second dimension ends at 65535
         const int n = min(65535, n_images - first);
         hipLaunchKernelGGL(k_pad_edges, dim3((unsigned)((px + 255) / 256), (unsigned)n), dim3(256), 0, s,
@@ -1489,8 +1490,11 @@ hipError_t static_workspace(void** ptr) {
 // This file is compiled twice.  The variants of k_encode_chunks with a quantiser are built in a translation
 // unit of their own (-DJPEGENC_TU_QUANT) with the scheduler's max-ILP strategy: there it removes their spills
 // (9 % faster), while the variants for the all-ones tables lose 5 % under it and keep the default strategy.
+// (Every launcher first takes any error an earlier, unrelated HIP call has left pending: what it returns is
+// then the outcome of its own launch.)
 template <int ALIGN, bool QUANT, int REGION, bool FUSED = false>
 static hipError_t launch_encode_b(const EncodeParams& p, dim3 grid, hipStream_t s) {
+    (void)hipGetLastError();
     if (p.flags & 1u)
         hipLaunchKernelGGL((k_encode_chunks<ALIGN, QUANT, true, REGION, FUSED>), grid, dim3(64), 0, s, p);
     else
@@ -1531,11 +1535,13 @@ hipError_t launch_encode(const EncodeParams& p_in, uint32_t n_images, int align,
 }
 
 hipError_t launch_scan(const ScanParams& p, uint32_t n_images, hipStream_t s) {
+    (void)hipGetLastError();
     hipLaunchKernelGGL(k_scan, dim3(n_images), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
 hipError_t launch_stuff_count(const StuffParams& p, uint32_t n_images, hipStream_t s) {
+    (void)hipGetLastError();
     const uint32_t n_chunks = n_images * p.cpi;
     const dim3 grid((n_chunks + kStuffWaves - 1) / kStuffWaves), block(64 * kStuffWaves);
     if (p.spec_depth >= kStuffDepth)
@@ -1546,6 +1552,7 @@ hipError_t launch_stuff_count(const StuffParams& p, uint32_t n_images, hipStream
 }
 
 hipError_t launch_stuff_image(const StuffParams& p, uint32_t n_images, hipStream_t s) {
+    (void)hipGetLastError();
     const dim3 grid(n_images), block(64 * kImageWaves);
     if (p.spec_depth >= kStuffDepth)
         hipLaunchKernelGGL((k_stuff_image<kStuffDepth>), grid, block, 0, s, p);
@@ -1555,6 +1562,7 @@ hipError_t launch_stuff_image(const StuffParams& p, uint32_t n_images, hipStream
 }
 
 hipError_t launch_stuff_write(const StuffParams& p, uint32_t n_images, hipStream_t s) {
+    (void)hipGetLastError();
     const uint32_t n_chunks = n_images * p.cpi;
     const dim3 grid((n_chunks + kStuffWaves - 1) / kStuffWaves), block(64 * kStuffWaves);
     if (p.spec_depth >= kStuffDepth)
