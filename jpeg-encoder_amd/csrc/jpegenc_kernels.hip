@@ -983,19 +983,27 @@ __global__ __launch_bounds__(64, REGION > kRegionSmall ? 2 : 3) void k_encode_ch
     // words per lane: four).  Lanes outside the range of a pass compute along and store nothing.
     bool fit = false;
     uint32_t lo = 0, hi = 64;             // lanes coded by this pass (uniform)
-    uint32_t need = 0, need_before = 0;   // fit: words of this lane's region, and of all lanes before it
+    // fit: the words of every lane's region wait in the LDS behind the regions (the room of the first pass's
+    // overrun, which the guarded passes never touch), not in a register across the passes
+    uint32_t* const need_lds = priv + 64 * kRegionWords;
+    static_assert(kPrivWords - 64 * kRegionWords >= 64, "room for 64 region sizes");
     for (;;) {
         const bool active = valid && (uint32_t)lane >= lo && (uint32_t)lane < hi;
-        const uint32_t cap = fit ? need - 2u : (uint32_t)kRegionWords - 2u;
         // region: word 0 takes the stores of the bit writer that are not meant to land, words [1, 1+cap)
         // the string, one more word the zero behind a full string; the lanes outside the range send all their
         // stores to word 0 of the first region
-        const uint32_t base = !fit ? (uint32_t)lane * kRegionWords
-                                   : (active ? need_before - readlane_u32(need_before, (int)lo) : 0u);
+        uint32_t base = (uint32_t)lane * kRegionWords;
         BitWriter bw;
+        bw.wlim = active ? (base + (uint32_t)kRegionWords - 1u) * 4u : base * 4u;
+        if (fit) {
+            const uint32_t need = need_lds[lane];
+            uint32_t need_total;
+            const uint32_t need_before = wave_excl_scan_u32(need, &need_total);
+            base = active ? need_before - readlane_u32(need_before, (int)lo) : 0u;
+            bw.wlim = active ? (base + need - 1u) * 4u : base * 4u;
+        }
         bw.win = 0;
         bw.T = base * 32u;
-        bw.wlim = active ? (base + 1u + cap) * 4u : base * 4u;
 
 #pragma unroll 1
         for (int comp = 0; comp < 3; ++comp) {
@@ -1054,6 +1062,7 @@ __global__ __launch_bounds__(64, REGION > kRegionSmall ? 2 : 3) void k_encode_ch
                 encode_block<true, QUANT>(x, pred, comp == 1 && cb_quirk, htab, hlen, priv, bw);
         }
         const uint32_t Lall = valid ? (bw.T - base * 32u) : 0u;
+        const uint32_t cap = fit ? need_lds[lane] - 2u : (uint32_t)kRegionWords - 2u;
         // flush the residual bits, left-aligned and zero-filled
         if (active && Lall <= cap * 32u) {
             if ((bw.T & 31u) != 0) priv[(bw.T >> 5) + 1u] = (uint32_t)bw.win << ((0u - bw.T) & 31u);
@@ -1072,12 +1081,11 @@ __global__ __launch_bounds__(64, REGION > kRegionSmall ? 2 : 3) void k_encode_ch
         }
         if (!fit && __any((int)(Lall > cap * 32u))) {
             // words per lane: the unread word 0, the string, the zero word behind it
-            need = ((Lall + 31u) >> 5) + 2u;
-            uint32_t need_total;
-            need_before = wave_excl_scan_u32(need, &need_total);
+            const uint32_t need = ((Lall + 31u) >> 5) + 2u;
+            need_lds[lane] = need;
             fit = true;
             lo = 0;
-            hi = fit_range_end(need_before + need, 0u, 0u, kFitWords);
+            hi = fit_range_end(wave_incl_scan_dpp(need), 0u, 0u, kFitWords);
             __syncthreads();
             continue;  // restart the chunk with exact regions
         }
@@ -1214,7 +1222,10 @@ __global__ __launch_bounds__(64, REGION > kRegionSmall ? 2 : 3) void k_encode_ch
         if (hi >= 64u) break;
         __syncthreads();  // LDS free for the next range of lanes
         lo = hi;
-        hi = fit_range_end(need_before + need, lo, readlane_u32(need_before, (int)lo), kFitWords);
+        {
+            const uint32_t need_incl = wave_incl_scan_dpp(need_lds[lane]);
+            hi = fit_range_end(need_incl, lo, readlane_u32(need_incl, (int)lo - 1), kFitWords);
+        }
     }
     // bit count (at most 64 * 4980 < 2^24) and, for the successor's first byte, the stream's last 8 bits
     if (!FUSED && lane == 0) p.chunk_bits[gid] = chunk_total | (tail8 << 24);
