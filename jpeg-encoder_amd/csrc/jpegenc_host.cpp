@@ -231,7 +231,7 @@ int pointer_align(const void* p, int64_t stride, int64_t image_stride, int n_ima
 // per call up to 16 frames, nothing gained from 32 on).  The sums are 32-bit: cpi * 318 720 bits must stay
 // below 2^32.
 constexpr uint32_t kStuffImageMinImages = 512;
-constexpr uint32_t kStuffImageMinChunks = 32;  // per image: its workgroup takes 16 chunks at a time
+constexpr uint32_t kStuffImageMinChunks = 32;  // per image: its workgroup takes 8 chunks at a time
 constexpr uint64_t kInlineScanChunks = 8192;
 constexpr uint32_t kInlineScanMaxCpi = 8192;
 
@@ -404,9 +404,9 @@ int run_group(jpegenc_ctx* ctx, const Workspace& ws, bool timed, const Plan& pl,
     rc_regions = collect_stats(ctx, ep);
     if (rc_regions != JPEGENC_OK) return rc_regions;
     // Many images: one workgroup per image does both stuffing steps in one launch and reads every chunk stream
-    // once.  Measured on 1080p batches against count + scan + write: 1.48 against 1.44 ms of kernel time per 1024
-    // frames but 0.3 to 1.5 % less per step (no scan launches, 2.3 GB less read), level at 256 frames, 8 % slower
-    // at 128 (too few workgroups): used from 512 images on.
+    // once.  Measured on 1080p batches against count + scan + write: 1.41 against 1.44 ms of kernel time per 1024
+    // frames, 1.5 to 3 % less per step (no scan launches, 2.3 GB less read); 0.73 against 0.74 ms at 512 frames;
+    // with too few workgroups it loses (16-wave workgroups: 8 % slower at 128 frames): used from 512 images on.
     const bool per_image = n >= kStuffImageMinImages && cpi >= kStuffImageMinChunks;
     // a frame or a few: the stuffing kernels work out the prefixes themselves, two launches fewer
     const bool inline_scan = !per_image && uint64_t(n) * cpi <= kInlineScanChunks && cpi <= kInlineScanMaxCpi;

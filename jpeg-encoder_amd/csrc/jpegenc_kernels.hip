@@ -1399,7 +1399,7 @@ __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_write(StuffParams p,
 
 // ------------------------------------------------------------------------------------------------
 // k_stuff_image: both stuffing steps for whole images in one launch, one workgroup of kImageWaves waves per
-// image.  The workgroup walks the image's chunks in order, kImageWaves at a time (one per wave): every wave
+// image (two such workgroups share a CU).  The workgroup walks the image's chunks in order, kImageWaves at a time (one per wave): every wave
 // requests its chunk, works out its bit offset from the counts of the round's earlier chunks, counts its
 // 0xFF bytes, and after one barrier -- the counts of the round stand in LDS -- writes its stuffed bytes.
 // The running bit offset and 0xFF count stay in registers, so no prefix arrays, no scan launches, and each
@@ -1408,7 +1408,7 @@ __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_write(StuffParams p,
 // chunks.  Both stuffing steps are bound by vector instructions (87 % of the write step's time), not by
 // memory, which is why reading the streams once buys so little.
 // ------------------------------------------------------------------------------------------------
-constexpr int kImageWaves = 16;
+constexpr int kImageWaves = 8;  // measured on 1024 x 1080p: 16 waves 1.49 ms, 8 waves 1.41 ms, 4 waves 1.40 ms (and 1.10 against 0.73 ms at 512 frames)
 
 template <int SPEC>
 __global__ __launch_bounds__(64 * kImageWaves) void k_stuff_image(StuffParams p) {
