@@ -64,6 +64,36 @@ def test_bad_arguments_are_rejected_without_touching_the_gpu():
     cfg.quirk_ydct_zext = 1
     ctx = C.c_void_p()
     assert lib.jpegenc_create(C.byref(ctx), C.byref(cfg)) == pkg.E_UNSUPPORTED
+    # every call that takes a context refuses a null one before it touches HIP
+    null = C.c_void_p()
+    assert lib.jpegenc_set_stream(null, None) == pkg.E_BAD_ARG
+    assert lib.jpegenc_synchronize(null) == pkg.E_BAD_ARG
+    assert lib.jpegenc_reserve(null, 1, 8, 8) == pkg.E_BAD_ARG
+    assert lib.jpegenc_set_pipeline(null, 0) == pkg.E_BAD_ARG
+    assert lib.jpegenc_set_region_mode(null, 0) == pkg.E_BAD_ARG
+    assert lib.jpegenc_set_workspace_limit(null, 1 << 20) == pkg.E_BAD_ARG
+    assert lib.jpegenc_encode_batch_noalloc(null, None, 1, 8, 8, 24, 192, None, 16, None) == pkg.E_BAD_ARG
+    assert lib.jpegenc_encode_batch(null, None, 1, 8, 8, 24, 192, 0, None, 16, None) == pkg.E_BAD_ARG
+    assert lib.jpegenc_segment_count(null, 0, 0, None) == pkg.E_BAD_ARG
+    assert lib.jpegenc_strerror(pkg.E_LIMIT) == b"call exceeds the static workspace of jpegenc_encode_batch_noalloc"
+    assert lib.jpegenc_strerror(pkg.E_NOMEM) == b"out of memory"
+
+
+def test_header_constants_match_the_python_mirror():
+    """The limits and codes the Python class repeats are the header's."""
+    pkg = load_pkg()
+    text = open(os.path.join(ROOT, "include", "jpegenc.h")).read()
+    defs = dict(re.findall(r"#define\s+(JPEGENC_[A-Z0-9_]+)\s+\(?(-?\d+)u?\)?", text))
+    assert int(defs["JPEGENC_NOALLOC_MAX_CHUNKS"]) == pkg.NOALLOC_MAX_CHUNKS
+    assert int(defs["JPEGENC_N_KERNELS"]) == 5
+    assert (int(defs["JPEGENC_E_LIMIT"]), int(defs["JPEGENC_E_NOMEM"]), int(defs["JPEGENC_E_STATE"])) == \
+           (pkg.E_LIMIT, pkg.E_NOMEM, pkg.E_STATE)
+    assert (int(defs["JPEGENC_PIPELINE_AUTO"]), int(defs["JPEGENC_PIPELINE_SPLIT"])) == \
+           (pkg.JpegTop.PIPELINE_AUTO, pkg.JpegTop.PIPELINE_SPLIT)
+    assert (int(defs["JPEGENC_REGIONS_AUTO"]), int(defs["JPEGENC_REGIONS_SMALL"]), int(defs["JPEGENC_REGIONS_LARGE"])) == \
+           (pkg.JpegTop.REGIONS_AUTO, pkg.JpegTop.REGIONS_SMALL, pkg.JpegTop.REGIONS_LARGE)
+    assert (int(defs["JPEGENC_DEVICE_PTRS"]), int(defs["JPEGENC_PAD_EDGES"]), int(defs["JPEGENC_SEG_CONTINUES"])) == \
+           (pkg.DEVICE_PTRS, pkg.PAD_EDGES, pkg.SEG_CONTINUES)
 
 
 def test_port_order_helper():
