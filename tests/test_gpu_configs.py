@@ -368,3 +368,50 @@ def test_many_images_take_the_per_image_stuffing_kernel():
 
     with ThreadPoolExecutor(8) as pool:
         list(pool.map(check, range(n)))
+
+
+def test_single_launch_calls_of_two_contexts_share_the_gpu():
+    """Two contexts on two streams, each queueing calls of four 1080p frames (2028 chunks: the single-launch
+    form at its limit).  Both launches cannot be resident together, so chunks of one wait for CUs while chunks of
+    the other wait for their predecessors' hand-off words: everything must still come out right, every time."""
+    pkg = load_pkg()
+    dev = torch.device("cuda:0")
+    h, w, n, reps = 1080, 1920, 4, 40
+    g = torch.Generator(device=dev)
+    g.manual_seed(77)
+    a = pkg.synth.natural_like_torch(n, h, w, 910, dev)
+    b = torch.randint(0, 256, (n, h, w, 3), generator=g, device=dev, dtype=torch.uint8)
+    b[:, :, :960] = pkg.synth.natural_like_torch(n, h, 960, 911, dev)  # half noise: chunks of very different duration
+    cap = w * h * 6 // 4
+    want = {}
+    with pkg.JpegTop(stream=torch.cuda.current_stream().cuda_stream) as e:
+        e.set_pipeline(e.PIPELINE_SPLIT)
+        for name, frames in (("a", a), ("b", b)):
+            d_words = torch.zeros((n, cap), dtype=torch.int32, device=dev)
+            d_res = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
+            e.encode_batch_device(frames.data_ptr(), n, w, h, w * 3, h * w * 3, d_words.data_ptr(), cap, d_res.data_ptr())
+            torch.cuda.synchronize()
+            want[name] = (d_words, d_res)
+    res = d_res.cpu().numpy().view(pkg.RESULT_DTYPE).reshape(n)
+    k = int(res[0]["n_full_words"]) + (1 if res[0]["tail_bits"] else 0)
+    same_as_oracle(want["b"][0][0, :k].cpu().numpy().view(np.uint32), res[0], b[0].cpu().numpy())
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    outs = {"a": [], "b": []}
+    torch.cuda.synchronize()
+    with pkg.JpegTop(stream=s1.cuda_stream) as ea, pkg.JpegTop(stream=s2.cuda_stream) as eb:
+        for rep in range(reps):
+            for name, e, frames in (("a", ea, a), ("b", eb, b)):
+                d_words = torch.zeros((n, cap), dtype=torch.int32, device=dev)
+                d_res = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
+                outs[name].append((d_words, d_res))
+            torch.cuda.synchronize()  # the buffers are zeroed before the two streams start on them
+            for name, e, frames in (("a", ea, a), ("b", eb, b)):
+                d_words, d_res = outs[name][-1]
+                e.encode_batch_device(frames.data_ptr(), n, w, h, w * 3, h * w * 3, d_words.data_ptr(), cap, d_res.data_ptr())
+            if rep % 8 == 7:
+                torch.cuda.synchronize()
+                for name in ("a", "b"):
+                    for d_words, d_res in outs[name]:
+                        assert torch.equal(d_res, want[name][1]) and torch.equal(d_words, want[name][0])
+                    outs[name].clear()
+        torch.cuda.synchronize()
