@@ -234,6 +234,9 @@ def main():
                    "sharding": "independent images, no collective"},
         "all_images_ok": ok, "out_bytes_per_pixel": round(out_bytes_per_px, 4),
     }
+    over_small, over_large, counted = enc.region_stats()
+    if counted:  # chunks of the last counted launch that hold an MCU too long for a small / large LDS region
+        line["chunks_over_region"] = {"small": round(over_small / counted, 4), "large": round(over_large / counted, 4)}
     failed = not ok
     if rank == 0:
         # Rooflines from the live HIP-event durations of this run (events recorded by the library on its stream).

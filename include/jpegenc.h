@@ -228,6 +228,11 @@ int jpegenc_set_pipeline(jpegenc_ctx* ctx, int mode);
 #define JPEGENC_REGIONS_SMALL 1
 #define JPEGENC_REGIONS_LARGE 2
 int jpegenc_set_region_mode(jpegenc_ctx* ctx, int mode);
+/* The counts behind that choice, as the last finished launch that collected them left them (calls of at most
+ * 2048 groups and calls with quantisation tables or unaligned rows collect none): counts[0] = groups of 64
+ * blocks with a block too long for a small region, counts[1] = with one too long for a large region,
+ * counts[2] = groups of that launch.  Read after jpegenc_synchronize for figures of a particular call. */
+int jpegenc_region_stats(jpegenc_ctx* ctx, uint64_t counts[3]);
 
 /* Grows the workspace now to what jpegenc_encode_batch(n_images, w, h) will need (under the limit
  * above), so that later device-pointer calls of at most that size only enqueue work: no allocation, no

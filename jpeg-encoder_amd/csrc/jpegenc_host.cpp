@@ -1080,6 +1080,18 @@ int jpegenc_set_pipeline(jpegenc_ctx* ctx, int mode) {
     return JPEGENC_OK;
 }
 
+int jpegenc_region_stats(jpegenc_ctx* ctx, uint64_t counts[3]) {
+    if (!ctx || !counts) return JPEGENC_E_BAD_ARG;
+    const volatile uint32_t* h = ctx->stats_host;
+    counts[0] = counts[1] = 0;
+    for (int i = 0; i < 16; ++i) {
+        counts[0] += h[16 * i];
+        counts[1] += h[16 * i + 1];
+    }
+    counts[2] = h[16 * 16];
+    return JPEGENC_OK;
+}
+
 int jpegenc_set_region_mode(jpegenc_ctx* ctx, int mode) {
     if (!ctx || mode < JPEGENC_REGIONS_AUTO || mode > JPEGENC_REGIONS_LARGE) return JPEGENC_E_BAD_ARG;
     ctx->region_mode = mode;

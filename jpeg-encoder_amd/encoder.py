@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "jpegenc_encode_stripes", "jpegenc_reset",
     "jpegenc_push_pixel", "jpegenc_push_pixels", "jpegenc_end_of_file", "jpegenc_read_words",
     "jpegenc_words_to_bytes", "jpegenc_set_profiling", "jpegenc_kernel_times", "jpegenc_kernel_name",
-    "jpegenc_set_workspace_limit", "jpegenc_set_region_mode", "jpegenc_set_pipeline", "jpegenc_reserve", "jpegenc_segment_encode", "jpegenc_segment_count",
+    "jpegenc_set_workspace_limit", "jpegenc_set_region_mode", "jpegenc_region_stats", "jpegenc_set_pipeline", "jpegenc_reserve", "jpegenc_segment_encode", "jpegenc_segment_count",
     "jpegenc_segment_write", "jpegenc_strerror", "jpegenc_last_error", "jpegenc_version",
 ]
 
@@ -101,6 +101,7 @@ def load_library(path=None):
     L.jpegenc_reserve.argtypes = [vp, i32, i32, i32]
     L.jpegenc_set_region_mode.argtypes = [vp, i32]
     L.jpegenc_set_pipeline.argtypes = [vp, i32]
+    L.jpegenc_region_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
     u64 = C.c_uint64
     L.jpegenc_segment_encode.argtypes = [vp, vp, i32, i32, C.c_ssize_t, u32, C.POINTER(u64), C.POINTER(u32)]
     L.jpegenc_segment_count.argtypes = [vp, u64, u32, C.POINTER(u64)]
@@ -191,6 +192,13 @@ class JpegTop:
     def set_pipeline(self, mode):
         """PIPELINE_AUTO (default): small calls run as one kernel launch; PIPELINE_SPLIT: always separate kernels."""
         self._check(self.lib.jpegenc_set_pipeline(self._ctx, int(mode)))
+
+    def region_stats(self):
+        """(groups with a block too long for a small region, ... for a large region, groups) of the last launch
+        that collected them."""
+        c = (C.c_uint64 * 3)()
+        self._check(self.lib.jpegenc_region_stats(self._ctx, c))
+        return int(c[0]), int(c[1]), int(c[2])
 
     def reserve(self, n_images, w, h):
         """Grows the workspace now, so that device-pointer calls of up to this size only enqueue work."""
