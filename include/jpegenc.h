@@ -217,13 +217,13 @@ int jpegenc_set_workspace_limit(jpegenc_ctx* ctx, size_t bytes);
 int jpegenc_set_pipeline(jpegenc_ctx* ctx, int mode);
 
 /* How the encode kernel sizes the per-block staging regions in LDS.  No counterpart in jpeg_top and no
- * effect on the output: only on speed.  Small regions (1248 bits per block of Y, Cb and Cr together) let
- * twelve wavefronts share a compute unit and are right for photographic content up to about 2 bytes per
- * pixel; a group of 64 blocks that holds a longer block is coded twice.  Large regions (2016 bits) never
- * need that below about 3.9 bytes per pixel and cost 9 % where small ones suffice.  AUTO (default): the
- * kernel counts, in every launch, the groups with a block too long for a small and for a large region, and
- * the context uses for the next launches whichever size those counts make cheaper (from about 12 % of the
- * groups too long for small regions on: large; content like uniform noise, too long for both: small). */
+ * effect on the output: only on speed.  Small regions (1440 bits per block of Y, Cb and Cr together) let
+ * twelve wavefronts share a compute unit and are right for photographic content up to about 2.5 bytes per
+ * pixel; a group of 64 blocks that holds a longer block is coded twice.  Large regions (2272 bits, more than
+ * a block of uniform noise needs on average) leave room for eight wavefronts and cost 15 % where small ones
+ * suffice.  AUTO (default): the kernel counts, in every launch, the groups with a block too long for a small
+ * and for a large region, and the context uses for the next launches whichever size those counts make
+ * cheaper (large from about 3 to 4 % of the groups too long for small regions on). */
 #define JPEGENC_REGIONS_AUTO 0
 #define JPEGENC_REGIONS_SMALL 1
 #define JPEGENC_REGIONS_LARGE 2

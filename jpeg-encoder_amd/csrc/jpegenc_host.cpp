@@ -320,12 +320,16 @@ int choose_regions(jpegenc_ctx* ctx, EncodeParams* ep, int align, uint64_t chunk
         }
         const uint64_t total = h[16 * 16];
         if (total >= 256 && over_large <= over_small && over_small <= total) {
-            // A chunk with an MCU too long for its region costs a second pass; large regions cost every chunk
-            // about 9 % (two waves per SIMD instead of three).  Per 100 chunks: 100 + over_small passes against
-            // 109 + 1.09 over_large; the margins keep a launch near the break-even from flipping back and forth.
-            const uint64_t small_cost = 100 * (total + over_small), large_cost = 109 * (total + over_large);
-            if (!ctx->large_regions && small_cost * 100 > large_cost * 103) ctx->large_regions = true;
-            if (ctx->large_regions && small_cost * 103 < large_cost * 100) ctx->large_regions = false;
+            // A chunk with an MCU too long for its region is coded again, and the other waves of its workgroup
+            // (four with small regions, two with large ones) hold their LDS idle meanwhile: a workgroup with any
+            // such chunk costs about 2.15 times one without.  Large regions cost every chunk about 15 % (two waves
+            // per SIMD instead of three).  Measured break-even: 3 to 4 % of the chunks too long for a small
+            // region.  The margin keeps a launch near the break-even from flipping back and forth.
+            const double qs = 1.0 - double(over_small) / double(total), ql = 1.0 - double(over_large) / double(total);
+            const double small_cost = 1.0 + 1.15 * (1.0 - qs * qs * qs * qs);
+            const double large_cost = 1.15 * (1.0 + 1.15 * (1.0 - ql * ql));
+            if (!ctx->large_regions && small_cost > large_cost * 1.02) ctx->large_regions = true;
+            if (ctx->large_regions && small_cost * 1.02 < large_cost) ctx->large_regions = false;
         }
     } else {
         ctx->large_regions = ctx->region_mode == JPEGENC_REGIONS_LARGE;
@@ -784,8 +788,12 @@ int jpegenc_encode_batch_noalloc(jpegenc_ctx* ctx, const uint8_t* rgb, int n_ima
     ws.chunk_bits = reinterpret_cast<uint32_t*>(ws.ff_off + kStaticChunks);
     ws.chunk_ff = ws.chunk_bits + kStaticChunks;
     // one launch group; no events are created (timed = false), nothing is allocated, staged or synchronised
-    return run_group(ctx, ws, false, pl, rgb, uint32_t(n_images), stride, image_stride,
-                     pointer_align(rgb, stride, image_stride, n_images, h), words_out, cap_words_per_image, results);
+    rc = run_group(ctx, ws, false, pl, rgb, uint32_t(n_images), stride, image_stride,
+                   pointer_align(rgb, stride, image_stride, n_images, h), words_out, cap_words_per_image, results);
+    if (rc != JPEGENC_OK) return rc;
+    // the hand-off words and statistics it used are the context's own: a later call on another stream
+    // (jpegenc_set_stream) has to wait for this one like for any other (recording an event allocates nothing)
+    return workspace_used(ctx);
 }
 
 int jpegenc_encode_rgb8(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int h, ptrdiff_t stride, uint32_t flags,

@@ -862,15 +862,24 @@ __device__ __forceinline__ Gathered gather_states(const uint64_t* st, uint32_t c
 // ------------------------------------------------------------------------------------------------
 // k_encode_chunks
 // ------------------------------------------------------------------------------------------------
-// LDS budget: 64 regions of REGION words plus the Huffman table.  REGION = 41 lets twelve workgroups (three
-// waves per SIMD) share the 160 KB of a CU: the first pass gives every lane one region (39 usable words = 1248
-// bits per MCU, 2.4 bytes per pixel: enough for photographic content); if any lane overflows, the chunk is
-// redone with regions cut to the lengths the first pass has counted.  REGION = 65 (63 usable words = 2016
-// bits, 3.9 bytes per pixel) is for content that would overflow often: eight workgroups per CU, 9 % slower
-// where 41 words suffice and up to twice as fast where they do not.  The host picks one per launch from the
-// overflow counts of its previous launches (see EncodeParams::stats).  Odd region strides keep lanes on
-// different LDS banks.
-[[maybe_unused]] constexpr int kRegionSmall = 41, kRegionLarge = 65;
+// LDS budget: per wave 64 regions of REGION words (one per lane, for the first pass), per workgroup one Huffman
+// table.  The first pass gives every lane one region; if any lane overflows, the chunk is redone with regions cut
+// to the lengths the first pass has counted.  Three sizes, measured on 1080p batches:
+//   small  47 words (45 usable = 1440 bits per MCU, 2.8 bytes per pixel), four waves per workgroup sharing the
+//          table: three workgroups = twelve waves per CU (three per SIMD).  Enough for photographic content.
+//          (41 words with one wave per workgroup is the same speed or 1 % slower and overflows from 2.0 bytes per
+//          pixel on; 49 words no longer fit three workgroups, 20 % slower.)
+//   large  73 words (71 usable = 2272 bits, 4.4 bytes per pixel), two waves per workgroup, four workgroups = eight
+//          waves per CU: 15 % slower where small regions suffice, up to twice as fast where they do not (uniform
+//          noise, 2150 bits per MCU on average, is done in one pass: 181 against 85 Gpixel/s with 65 words).
+//          (Four waves per workgroup: 8 % slower; one wave, seven per CU: 7 % slower.)
+//   single-launch form: 65 words, one wave per workgroup, eight per CU, which is what makes 2048 chunks resident.
+// The host picks small or large per launch from the overflow counts of its previous launches (see
+// EncodeParams::stats).  The variants off the common path (quantising: short streams; rows not 8-byte aligned)
+// keep 41 words and one wave per workgroup, twelve per CU: with 47 words they would spill registers.  Odd region
+// strides keep lanes on different LDS banks.
+[[maybe_unused]] constexpr int kRegionBasic = 41, kRegionSmall = 47, kRegionFused = 65, kRegionLarge = 73;
+[[maybe_unused]] constexpr int kSmallWaves = 4, kLargeWaves = 2;  // per workgroup
 constexpr uint32_t kSmallRegionBits = (kRegionSmall - 2) * 32;  // what a lane may emit in a small region
 constexpr uint32_t kLargeRegionBits = (kRegionLarge - 2) * 32;
 
@@ -883,41 +892,63 @@ __device__ __forceinline__ uint32_t fit_range_end(uint32_t need_incl, uint32_t l
     return lo + (uint32_t)__popcll(fits);
 }
 
-template <int ALIGN, bool QUANT, bool WRAP, int REGION, bool FUSED>
-__global__ __launch_bounds__(64, REGION > kRegionSmall ? 2 : 3) void k_encode_chunks(EncodeParams p) {
+template <int ALIGN, bool QUANT, bool WRAP, int REGION, bool FUSED, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_encode_chunks(EncodeParams p) {
     constexpr int kRegionWords = REGION;
     constexpr int kOwnWords = kRegionWords - 1;  // first pass: REGION - 2 usable words and one zero word behind them
-    static_assert(kOwnWords % 8 == 0, "the in-register concatenation works in blocks of 8 words");
-    // The regions plus room for the unguarded overrun of the last lane in the first pass (156 words from its base).
-    constexpr int kPrivWords = 64 * kRegionWords + 120;
+    constexpr int kOwnRegs = (kOwnWords + 7) & ~7;  // the in-register concatenation works in blocks of 8 words
+    static_assert(!FUSED || WAVES == 1, "the single-launch form turns the table's place into its wave's stage");
+    // behind the regions: room for the unguarded overrun of the last lane in the first pass (kMaxMcuWords from its
+    // base), which later holds the 64 region sizes of the exact-fit passes
+    constexpr int kPadWords = ((kMaxMcuWords - REGION > 64 ? kMaxMcuWords - REGION : 64) + 3) & ~3;
+    constexpr int kPrivWords = 64 * kRegionWords + kPadWords;
+    static_assert(kPrivWords % 4 == 0, "every wave's part starts on a 16-byte boundary");
     static_assert(63 * kRegionWords + kMaxMcuWords <= kPrivWords, "first-pass overrun of the last lane");
     constexpr uint32_t kFitWords = 64 * kRegionWords;  // what the exact regions of one pass may add up to
     static_assert(kFitWords >= 16 * (kMaxMcuWords + 2), "a pass holds at least 16 worst-case MCUs");
-    __shared__ __attribute__((aligned(16))) uint32_t priv[kPrivWords];
+    // One wave codes one chunk in LDS of its own; the waves of a workgroup share the Huffman table only.  `flat`
+    // is all of it (the bit writer's addresses count from there: a constant base costs no instruction per store),
+    // `priv` this wave's part.
+    __shared__ __attribute__((aligned(16))) uint32_t flat[WAVES * kPrivWords];
+    const uint32_t wave = WAVES > 1 ? threadIdx.x >> 6 : 0u;
+    const uint32_t woff = wave * (uint32_t)kPrivWords;
+    uint32_t* const priv = flat + woff;
     // the Huffman table: code << size as words, then code length + size as bytes (one array: the single-launch
     // form reuses it as the stage of the stuffing step)
     __shared__ __attribute__((aligned(16))) uint32_t tables[kHtabEntries + kHtabEntries / 4];
     uint32_t* const htab = tables;
     uint8_t* const hlen = reinterpret_cast<uint8_t*>(tables + kHtabEntries);
     static_assert(!FUSED || sizeof(tables) >= kStageBytes, "the stage fits the table's place");
-    const int lane = threadIdx.x;
-    // grid: x = chunk of the image, y and z = image (no division)
-    const uint32_t c = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    // grid: x = chunk of the image (WAVES of them per workgroup), y and z = image (no division)
+    const uint32_t c = blockIdx.x * WAVES + wave;
     const uint32_t img = blockIdx.z * 65535u + blockIdx.y;
-    if (img >= p.n_images) return;
+    if (img >= p.n_images) return;  // (the whole workgroup)
     const uint32_t gid = img * p.cpi + c;
+    // within one wave the LDS needs no barrier, only program order
+    auto sync_wave = [] {
+        if constexpr (WAVES == 1)
+            __syncthreads();
+        else
+            wave_sync();
+    };
     const bool cb_quirk = (p.flags & 2u) != 0;
 
     {
-        static_assert(kHtabEntries % 64 == 0, "whole rounds of 64 lanes");
-        uint32_t e[kHtabEntries / 64];  // all loads in flight at once
+        constexpr int kThreads = 64 * WAVES;
+        static_assert(kHtabEntries % kThreads == 0, "whole rounds of the workgroup");
+        uint32_t e[kHtabEntries / kThreads];  // all loads in flight at once
 #pragma unroll
-        for (int j = 0; j < kHtabEntries / 64; ++j) e[j] = p.htab[lane + 64 * j];
+        for (int j = 0; j < kHtabEntries / kThreads; ++j) e[j] = p.htab[threadIdx.x + kThreads * j];
 #pragma unroll
-        for (int j = 0; j < kHtabEntries / 64; ++j) {
-            htab[lane + 64 * j] = e[j] & 0x7FFFFFFu;
-            hlen[lane + 64 * j] = (uint8_t)(e[j] >> 27);
+        for (int j = 0; j < kHtabEntries / kThreads; ++j) {
+            htab[threadIdx.x + kThreads * j] = e[j] & 0x7FFFFFFu;
+            hlen[threadIdx.x + kThreads * j] = (uint8_t)(e[j] >> 27);
         }
+    }
+    if (WAVES > 1 && c >= p.cpi) {  // a wave behind the image's last chunk: only the table's barrier is its business
+        __syncthreads();
+        return;
     }
 
     // MCU coordinates: one division for the chunk's first MCU (wave-uniform); a lane's own follow from its
@@ -992,14 +1023,14 @@ __global__ __launch_bounds__(64, REGION > kRegionSmall ? 2 : 3) void k_encode_ch
         // region: word 0 takes the stores of the bit writer that are not meant to land, words [1, 1+cap)
         // the string, one more word the zero behind a full string; the lanes outside the range send all their
         // stores to word 0 of the first region
-        uint32_t base = (uint32_t)lane * kRegionWords;
+        uint32_t base = woff + (uint32_t)lane * kRegionWords;  // (index into flat)
         BitWriter bw;
         bw.wlim = active ? (base + (uint32_t)kRegionWords - 1u) * 4u : base * 4u;
         if (fit) {
             const uint32_t need = need_lds[lane];
             uint32_t need_total;
             const uint32_t need_before = wave_excl_scan_u32(need, &need_total);
-            base = active ? need_before - readlane_u32(need_before, (int)lo) : 0u;
+            base = woff + (active ? need_before - readlane_u32(need_before, (int)lo) : 0u);
             bw.wlim = active ? (base + need - 1u) * 4u : base * 4u;
         }
         bw.win = 0;
@@ -1057,16 +1088,16 @@ __global__ __launch_bounds__(64, REGION > kRegionSmall ? 2 : 3) void k_encode_ch
             // DC of the lane before; lane 0 has no source and keeps h (wave_shr:1)
             const int pred = __builtin_amdgcn_update_dpp(h, x[0], 0x138, 0xF, 0xF, false);
             if (!fit)
-                encode_block<false, QUANT>(x, pred, comp == 1 && cb_quirk, htab, hlen, priv, bw);
+                encode_block<false, QUANT>(x, pred, comp == 1 && cb_quirk, htab, hlen, flat, bw);
             else
-                encode_block<true, QUANT>(x, pred, comp == 1 && cb_quirk, htab, hlen, priv, bw);
+                encode_block<true, QUANT>(x, pred, comp == 1 && cb_quirk, htab, hlen, flat, bw);
         }
         const uint32_t Lall = valid ? (bw.T - base * 32u) : 0u;
         const uint32_t cap = fit ? need_lds[lane] - 2u : (uint32_t)kRegionWords - 2u;
         // flush the residual bits, left-aligned and zero-filled
         if (active && Lall <= cap * 32u) {
-            if ((bw.T & 31u) != 0) priv[(bw.T >> 5) + 1u] = (uint32_t)bw.win << ((0u - bw.T) & 31u);
-            priv[((bw.T + 31u) >> 5) + 1u] = 0u;  // one zero word behind the string
+            if ((bw.T & 31u) != 0) flat[(bw.T >> 5) + 1u] = (uint32_t)bw.win << ((0u - bw.T) & 31u);
+            flat[((bw.T + 31u) >> 5) + 1u] = 0u;  // one zero word behind the string
         }
         if (!fit && p.stats) {
             // for the host's choice of REGION: chunks with an MCU beyond the small region, spread over 16
@@ -1086,11 +1117,11 @@ __global__ __launch_bounds__(64, REGION > kRegionSmall ? 2 : 3) void k_encode_ch
             fit = true;
             lo = 0;
             hi = fit_range_end(wave_incl_scan_dpp(need), 0u, 0u, kFitWords);
-            __syncthreads();
+            sync_wave();
             continue;  // restart the chunk with exact regions
         }
         const uint32_t L = active ? Lall : 0u;  // bits of this lane's string in this pass
-        __syncthreads();  // strings visible to all lanes
+        sync_wave();  // strings visible to all lanes
 
         // ---- concatenate the strings of this pass in place, in lane order, at LDS word 0 ----------
         // Destination word d0+t is (src[t-1]:src[t]) >> s; the bits a string shares with its predecessor's
@@ -1107,9 +1138,9 @@ __global__ __launch_bounds__(64, REGION > kRegionSmall ? 2 : 3) void k_encode_ch
             const uint32_t s = off & 31u, j0 = off >> 5;
             const uint32_t nd = L ? ((s + L + 31u) >> 5) : 0u;  // destination words touched
             const uint32_t nmax = wave_max_u32(nd);             // uniform, <= kOwnWords
-            uint32_t own[kOwnWords];
+            uint32_t own[kOwnRegs];  // (the words past kOwnWords are read and never used)
 #pragma unroll
-            for (int t = 0; t < kOwnWords; ++t) own[t] = priv[base + 1 + t];
+            for (int t = 0; t < kOwnRegs; ++t) own[t] = flat[base + 1 + t];
             wave_sync();
             // (The four-word forms here and in the slot copy below are left out of the quantising variants:
             // their streams are short, and at the register limit the allocator then spills more.)
@@ -1121,7 +1152,7 @@ __global__ __launch_bounds__(64, REGION > kRegionSmall ? 2 : 3) void k_encode_ch
             }
             wave_sync();
 #pragma unroll
-            for (int t0 = 0; t0 < kOwnWords; t0 += 8) {
+            for (int t0 = 0; t0 < kOwnRegs; t0 += 8) {
                 if ((uint32_t)t0 < nmax) {
 #pragma unroll
                     for (int t = t0; t < t0 + 8; ++t) {
@@ -1144,26 +1175,26 @@ __global__ __launch_bounds__(64, REGION > kRegionSmall ? 2 : 3) void k_encode_ch
             const uint32_t nd = (s + LM + 31u) >> 5;  // destination words touched
             if (nd <= 64u) {
                 const uint32_t t = lane;
-                const uint32_t wlo = (t < nw) ? priv[bM + t] : 0u;
+                const uint32_t wlo = (t < nw) ? flat[bM + t] : 0u;
                 uint32_t whi = __shfl_up(wlo, 1);
                 if (t == 0) whi = 0u;
                 uint32_t w = __builtin_amdgcn_alignbit(whi, wlo, s);
                 if (t == 0) w |= tailw;
-                __syncthreads();  // all reads of this step before its writes
+                sync_wave();  // all reads of this step before its writes
                 if (t < nd) priv[d0 + t] = w;
                 tailw = ((s + LM) & 31u) ? readlane_u32(w, (int)nd - 1) : 0u;
-                __syncthreads();
+                sync_wave();
             } else {
                 for (uint32_t t0 = 0; t0 < nd; t0 += 64) {
                     const uint32_t t = t0 + lane;
-                    const uint32_t wlo = (t < nw) ? priv[bM + t] : 0u;
-                    const uint32_t whi = (t >= 1 && t - 1 < nw) ? priv[bM + t - 1] : 0u;
+                    const uint32_t wlo = (t < nw) ? flat[bM + t] : 0u;
+                    const uint32_t whi = (t >= 1 && t - 1 < nw) ? flat[bM + t - 1] : 0u;
                     uint32_t w = __builtin_amdgcn_alignbit(whi, wlo, s);
                     if (t == 0) w |= tailw;
-                    __syncthreads();
+                    sync_wave();
                     if (t < nd) priv[d0 + t] = w;
                     if (t0 + 64 >= nd) tailw = ((s + LM) & 31u) ? readlane_u32(w, (int)(nd - 1 - t0)) : 0u;
-                    __syncthreads();
+                    sync_wave();
                 }
             }
         }
@@ -1220,7 +1251,7 @@ __global__ __launch_bounds__(64, REGION > kRegionSmall ? 2 : 3) void k_encode_ch
             chunk_total = nt;
         }
         if (hi >= 64u) break;
-        __syncthreads();  // LDS free for the next range of lanes
+        sync_wave();  // LDS free for the next range of lanes
         lo = hi;
         {
             const uint32_t need_incl = wave_incl_scan_dpp(need_lds[lane]);
@@ -1503,21 +1534,22 @@ hipError_t static_workspace(void** ptr) {
 // (9 % faster), while the variants for the all-ones tables lose 5 % under it and keep the default strategy.
 // (Every launcher first takes any error an earlier, unrelated HIP call has left pending: what it returns is
 // then the outcome of its own launch.)
-template <int ALIGN, bool QUANT, int REGION, bool FUSED = false>
+template <int ALIGN, bool QUANT, int REGION, bool FUSED = false, int WAVES = 1>
 static hipError_t launch_encode_b(const EncodeParams& p, dim3 grid, hipStream_t s) {
     (void)hipGetLastError();
+    grid.x = (grid.x + WAVES - 1) / WAVES;  // WAVES chunks per workgroup
     if (p.flags & 1u)
-        hipLaunchKernelGGL((k_encode_chunks<ALIGN, QUANT, true, REGION, FUSED>), grid, dim3(64), 0, s, p);
+        hipLaunchKernelGGL((k_encode_chunks<ALIGN, QUANT, true, REGION, FUSED, WAVES>), grid, dim3(64 * WAVES), 0, s, p);
     else
-        hipLaunchKernelGGL((k_encode_chunks<ALIGN, QUANT, false, REGION, FUSED>), grid, dim3(64), 0, s, p);
+        hipLaunchKernelGGL((k_encode_chunks<ALIGN, QUANT, false, REGION, FUSED, WAVES>), grid, dim3(64 * WAVES), 0, s, p);
     return hipGetLastError();
 }
 
 #ifdef JPEGENC_TU_QUANT
 hipError_t launch_encode_quant(const EncodeParams& p, dim3 grid, int align, hipStream_t s) {
-    if (align >= 8) return launch_encode_b<8, true, kRegionSmall>(p, grid, s);
-    if (align >= 4) return launch_encode_b<4, true, kRegionSmall>(p, grid, s);
-    return launch_encode_b<1, true, kRegionSmall>(p, grid, s);
+    if (align >= 8) return launch_encode_b<8, true, kRegionBasic>(p, grid, s);
+    if (align >= 4) return launch_encode_b<4, true, kRegionBasic>(p, grid, s);
+    return launch_encode_b<1, true, kRegionBasic>(p, grid, s);
 }
 #else
 hipError_t launch_encode_quant(const EncodeParams& p, dim3 grid, int align, hipStream_t s);
@@ -1533,16 +1565,17 @@ hipError_t launch_encode(const EncodeParams& p_in, uint32_t n_images, int align,
     if (nz > 65535u) return hipErrorInvalidValue;
     const dim3 grid(p.cpi, ny, nz);
     if (p.state) {
-        // single-launch form: only the common variant, with large regions (a launch this small leaves most of
-        // the LDS unused anyway)
+        // single-launch form: only the common variant (a launch this small leaves most of the LDS unused anyway)
         if (p.qmul || align < 8 || chunks > kSingleLaunchMaxChunks) return hipErrorInvalidValue;
-        return launch_encode_b<8, false, kRegionLarge, true>(p, grid, s);
+        return launch_encode_b<8, false, kRegionFused, true>(p, grid, s);
     }
     if (p.qmul) return launch_encode_quant(p, grid, align, s);
     // large regions exist for the common variant only (8-byte-aligned rows, all-ones tables: quantised streams are short)
-    if (align >= 8) return p.large_regions ? launch_encode_b<8, false, kRegionLarge>(p, grid, s) : launch_encode_b<8, false, kRegionSmall>(p, grid, s);
-    if (align >= 4) return launch_encode_b<4, false, kRegionSmall>(p, grid, s);
-    return launch_encode_b<1, false, kRegionSmall>(p, grid, s);
+    if (align >= 8)
+        return p.large_regions ? launch_encode_b<8, false, kRegionLarge, false, kLargeWaves>(p, grid, s)
+                               : launch_encode_b<8, false, kRegionSmall, false, kSmallWaves>(p, grid, s);
+    if (align >= 4) return launch_encode_b<4, false, kRegionBasic>(p, grid, s);
+    return launch_encode_b<1, false, kRegionBasic>(p, grid, s);
 }
 
 hipError_t launch_scan(const ScanParams& p, uint32_t n_images, hipStream_t s) {

@@ -268,52 +268,61 @@ def test_segment_state_is_dropped_by_other_calls_and_one_chunk_last_band():
 
 
 def test_region_modes_give_the_same_stream():
-    """The encode kernel exists with small and with large LDS staging regions; the context picks one per launch
-    from the overflow counts of the launches before.  Whatever it picks, the words are the oracle's: easy,
-    detailed and noise content under both forced modes, and a run in automatic mode that starts on easy
-    content, meets detailed content (switches to large regions) and returns to easy content."""
+    """The encode kernel exists with small and with large LDS staging regions (and a third size in the
+    single-launch form); the context picks small or large per launch from the overflow counts of the launches
+    before.  Whatever runs, the words are the oracle's: easy, mixed (every other MCU row noise) and noise content
+    under both forced sizes and in the single-launch form, and a run in automatic mode that starts on easy
+    content, meets the others (switches to large regions) and returns to easy content.  The overflow counts the
+    choice rests on are checked too: none on easy content, every chunk on noise."""
     pkg = load_pkg()
     dev = torch.device("cuda:0")
-    h, w, n = 256, 1024, 6  # 6 x 64 chunks per call: enough for the automatic mode to act on
+    h, w, n = 256, 1024, 36  # 36 x 64 chunks per call: beyond what the single-launch form takes
     g = torch.Generator(device=dev)
     g.manual_seed(31)
     easy = pkg.synth.natural_like_torch(n, h, w, 40, dev)
-    keep = pkg.synth.PERSISTENCE
-    pkg.synth.PERSISTENCE = 3.0
-    try:
-        detailed = pkg.synth.natural_like_torch(n, h, w, 41, dev)
-    finally:
-        pkg.synth.PERSISTENCE = keep
     noise = torch.randint(0, 256, (n, h, w, 3), generator=g, device=dev, dtype=torch.uint8)
+    mixed = easy.clone()
+    mixed[:, 8::16] = noise[:, 8::16]  # rows 8, 24, ...: one pixel row of noise in every other MCU row
+    mixed[:, 12::16] = noise[:, 12::16]
     cap = pkg.max_words(w, h)
     want = {}
 
-    def run(e, name, frames):
-        d_words = torch.zeros((n, cap), dtype=torch.int32, device=dev)
-        d_res = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
-        e.encode_batch_device(frames.data_ptr(), n, w, h, w * 3, h * w * 3, d_words.data_ptr(), cap, d_res.data_ptr())
+    def run(e, name, frames, count=None):
+        k_img = frames.shape[0] if count is None else count
+        d_words = torch.zeros((k_img, cap), dtype=torch.int32, device=dev)
+        d_res = torch.zeros((k_img, 32), dtype=torch.uint8, device=dev)
+        e.encode_batch_device(frames.data_ptr(), k_img, w, h, w * 3, h * w * 3, d_words.data_ptr(), cap, d_res.data_ptr())
         torch.cuda.synchronize()
-        res = d_res.cpu().numpy().view(pkg.RESULT_DTYPE).reshape(n)
+        res = d_res.cpu().numpy().view(pkg.RESULT_DTYPE).reshape(k_img)
         assert (res["status"] == 0).all()
-        out = []
-        for i in range(n):
-            k = int(res[i]["n_full_words"]) + (1 if res[i]["tail_bits"] else 0)
-            out.append(d_words[i, :k].cpu().numpy().view(np.uint32))
         if name not in want:  # the oracle's words, once per content
             host = frames.cpu().numpy()
             want[name] = [O.encode(host[i])[0] for i in range(n)]
-        for i in range(n):
-            assert np.array_equal(out[i], want[name][i]), (name, i)
+        for i in range(k_img):
+            k = int(res[i]["n_full_words"]) + (1 if res[i]["tail_bits"] else 0)
+            assert np.array_equal(d_words[i, :k].cpu().numpy().view(np.uint32), want[name][i]), (name, i)
 
-    contents = (("easy", easy), ("detailed", detailed), ("noise", noise))
+    contents = (("easy", easy), ("mixed", mixed), ("noise", noise))
     for mode in (pkg.JpegTop.REGIONS_SMALL, pkg.JpegTop.REGIONS_LARGE):
         with pkg.JpegTop(stream=torch.cuda.current_stream().cuda_stream) as e:
             e.set_region_mode(mode)
             for name, frames in contents:
                 run(e, name, frames)
+                over_small, over_large, total = e.region_stats()
+                assert total == n * 64 and over_large <= over_small <= total
+                if name == "easy":
+                    assert over_small == 0
+                if name == "noise":
+                    assert over_small == total
+            e.set_pipeline(pkg.JpegTop.PIPELINE_SPLIT)  # a small call as separate kernels takes the forced size too
+            for name, frames in contents:
+                run(e, name, frames, 3)
+    with pkg.JpegTop(stream=torch.cuda.current_stream().cuda_stream) as e:  # the single-launch form
+        for name, frames in contents:
+            run(e, name, frames, 30)
     with pkg.JpegTop(stream=torch.cuda.current_stream().cuda_stream) as e:  # automatic
-        for name, frames in (contents[0], contents[1], contents[1], contents[1], contents[2], contents[0], contents[0],
-                             contents[0]):
+        for name, frames in (contents[0], contents[1], contents[1], contents[1], contents[2], contents[2], contents[0],
+                             contents[0], contents[0]):
             run(e, name, frames)
 
 

@@ -1,0 +1,9 @@
+for P in 3.7 4.0 4.3; do for R in small large auto; do
+timeout -k 10 200 python -u bench.py --steps 6 --warmup 2 --no-cpu --persistence $P --regions $R > gpurun_out/sw.log 2>&1 || { tail -5 gpurun_out/sw.log; exit 1; }
+python - $P $R <<'PY'
+import json, sys
+l = [x for x in open("gpurun_out/sw.log") if x.startswith("{")][-1]
+d = json.loads(l); k = d["kernel_ms_per_step"]
+print("P %s %-5s %7.0f Mpx/s enc %.3f over %s %.3f B/px" % (sys.argv[1], sys.argv[2], d["value"], k["k_encode_chunks"], d.get("chunks_over_region"), d["out_bytes_per_pixel"]))
+PY
+done; done
