@@ -19,5 +19,5 @@ run --frames 1 --steps 20 --content noise --cpu-frames 1
 run --frames 256 --width 3840 --height 2160 --cpu-frames 4
 run --frames 8 --width 16384 --height 2048 --cpu-frames 1
 run --content noise --no-cpu
-for p in 0.85 1.0 1.3 1.7 2.2 3.0; do run --frames 256 --persistence $p --cpu-frames 4; done
+for p in 0.85 1.0 1.3 1.7 2.2 3.0 4.0 5.0; do run --frames 256 --persistence $p --cpu-frames 4; done
 for q in 4 16 50; do run --frames 256 --quant $q --cpu-frames 8; done
