@@ -119,8 +119,9 @@ int jpegenc_encode_batch(jpegenc_ctx* ctx, const uint8_t* rgb, int n_images, int
 /* jpegenc_encode_batch for callers that cannot allocate device memory: code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference (hardware has no
  * allocator).  Device pointers only (rgb, words_out and results are device memory on the context's device);
- * same kernels, same output and the same per-image status as jpegenc_encode_batch with
- * JPEGENC_DEVICE_PTRS; only enqueues work on the context's stream.  It calls no hipMalloc/hipFree and no
+ * same output and the same per-image status as jpegenc_encode_batch with JPEGENC_DEVICE_PTRS; only
+ * enqueues work on the context's stream, always as the separate kernels (JPEGENC_PIPELINE_SPLIT: the
+ * single-launch form tags every launch, so a captured launch could not be replayed; these can).  It calls no hipMalloc/hipFree and no
  * other allocating routine (kernel timing, which creates events, is off for these calls): the intermediate
  * chunk streams live in a fixed array inside the library's code object, JPEGENC_NOALLOC_MAX_CHUNKS chunks
  * of 64 blocks (81.9 MB that every GPU the library runs on holds until the process ends).  A call needs

@@ -358,7 +358,8 @@ uint32_t next_generation() {
 }
 
 // The launches for n images (one launch group) with the workspace `ws`.  All pointers are device memory.
-// `timed`: bracket the kernels with events when profiling is on (creates events).
+// `timed`: bracket the kernels with events when profiling is on (creates events) and let small calls take the
+// single-launch form (whose launch carries a tag of its own, so that enqueued work cannot be replayed).
 int run_group(jpegenc_ctx* ctx, const Workspace& ws, bool timed, const Plan& pl, const uint8_t* rgb, uint32_t n,
               ptrdiff_t stride, ptrdiff_t image_stride, int align, uint32_t* words, size_t cap_words,
               jpegenc_result* results) {
@@ -390,7 +391,8 @@ int run_group(jpegenc_ctx* ctx, const Workspace& ws, bool timed, const Plan& pl,
     ep.results = results;
     // A frame or a few (every chunk resident at once), common kernel variant: one launch does it all -- each
     // chunk's wave waits for the counts of the chunks before it, then stuffs and writes its own stream.
-    if (ctx->pipeline == JPEGENC_PIPELINE_AUTO && uint64_t(n) * cpi <= kSingleLaunchMaxChunks && !ctx->quant && align >= 8) {
+    if (timed && ctx->pipeline == JPEGENC_PIPELINE_AUTO && uint64_t(n) * cpi <= kSingleLaunchMaxChunks && !ctx->quant &&
+        align >= 8) {
         ep.stats = nullptr;
         ep.large_regions = 1;
         ep.state = ctx->state.p;
@@ -787,7 +789,8 @@ int jpegenc_encode_batch_noalloc(jpegenc_ctx* ctx, const uint8_t* rgb, int n_ima
     ws.ff_off = ws.bit_off + kStaticChunks;
     ws.chunk_bits = reinterpret_cast<uint32_t*>(ws.ff_off + kStaticChunks);
     ws.chunk_ff = ws.chunk_bits + kStaticChunks;
-    // one launch group; no events are created (timed = false), nothing is allocated, staged or synchronised
+    // one launch group as separate kernels; no events are created (timed = false), nothing is allocated, staged
+    // or synchronised, and no launch argument changes from call to call for the same arguments
     rc = run_group(ctx, ws, false, pl, rgb, uint32_t(n_images), stride, image_stride,
                    pointer_align(rgb, stride, image_stride, n_images, h), words_out, cap_words_per_image, results);
     if (rc != JPEGENC_OK) return rc;

@@ -1,6 +1,8 @@
 """The entry point that allocates nothing (jpegenc_encode_batch_noalloc, static workspace inside the
 library) against jpegenc_encode_batch on the same inputs: word for word, through the C ABI, twice in a
-row with the second input smaller (the static array still holds the first call's contents)."""
+row with the second input smaller (the static array still holds the first call's contents); and the same entry
+point captured into a HIP graph (capture refuses allocation, so that also shows the call makes none) and
+replayed on new pixels in the same buffers."""
 import numpy as np
 import pytest
 
@@ -68,3 +70,44 @@ def test_noalloc_entry_point_matches_the_allocating_one():
     with pkg.JpegTop(stream=torch.cuda.current_stream().cuda_stream, qtabs=[[4] * 64] * 3) as e2:
         (w_ref, r_ref), (w_new, r_new) = run_both(pkg, e2, small, pkg.max_words(136, 72))
         assert (r_ref["status"] == 0).all() and r_new.tobytes() == r_ref.tobytes() and np.array_equal(w_new, w_ref)
+
+
+def test_noalloc_call_replays_from_a_captured_graph():
+    """The call captured once on a side stream, then replayed three times on other pixels in the same buffers:
+    every replay gives the oracle's words (nothing in the launches is tied to the call that was captured)."""
+    pkg = load_pkg()
+    dev = torch.device("cuda:0")
+    n, h, w = 3, 264, 520  # 3 x 34 chunks, the last one of an image partial
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    contents = [pkg.synth.natural_like_torch(n, h, w, 900, dev),
+                torch.randint(0, 256, (n, h, w, 3), generator=gen, device=dev, dtype=torch.uint8),
+                pkg.synth.natural_like_torch(n, h, w, 901, dev)]
+    cap = pkg.max_words(w, h)
+    buf = contents[0].clone()
+    d_words = torch.zeros((n, cap), dtype=torch.int32, device=dev)
+    d_res = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
+    side = torch.cuda.Stream()
+    args = (buf.data_ptr(), n, w, h, w * 3, h * w * 3, d_words.data_ptr(), cap, d_res.data_ptr())
+    with pkg.JpegTop(stream=side.cuda_stream) as e:
+        e.encode_batch_noalloc(*args)  # once outside capture: code objects loaded, nothing left to set up
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            e.encode_batch_noalloc(*args)
+        for frames in contents[1:] + contents[:1]:
+            buf.copy_(frames)
+            d_words.fill_(0x5A5A5A5A)
+            d_res.zero_()
+            torch.cuda.synchronize()
+            graph.replay()
+            torch.cuda.synchronize()
+            res = d_res.cpu().numpy().view(pkg.RESULT_DTYPE).reshape(n)
+            assert (res["status"] == 0).all()
+            host = frames.cpu().numpy()
+            for i in range(n):
+                want, r = O.encode(host[i])
+                k = int(res[i]["n_full_words"]) + (1 if res[i]["tail_bits"] else 0)
+                assert k == len(want) and np.array_equal(d_words[i, :k].cpu().numpy().view(np.uint32), want), i
+                assert int(res[i]["tail_word"]) == r.tail_word
+        del graph
