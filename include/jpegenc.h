@@ -136,6 +136,16 @@ int jpegenc_encode_batch_noalloc(jpegenc_ctx* ctx, const uint8_t* rgb, int n_ima
                                  ptrdiff_t image_stride, uint32_t* words_out, size_t cap_words_per_image,
                                  jpegenc_result* results);
 
+/* The stage before the entropy coders, for checking it on its own: the coefficients as the three Huffman
+ * coders receive them -- after rgb2ycrcb.sv:77-135, the two DCT passes (y_dct.sv, cb_dct.sv, cr_dct.sv), the
+ * quantisers (y_quantizer.sv:58-106 and twins) and the wrapper transpose (yd_q_h.sv:120-135), i.e. the nets
+ * between *_quantizer and *_huff that a testbench would probe.  coeffs_out[((by * (w/8) + bx) * 3 + c) * 64 +
+ * k]: 8x8 block (bx, by), component c (0 Y, 1 Cb, 2 Cr), k = position in the order the coder reads them
+ * (zig-zag, cr_huff.sv:1053-1304; k = 0 is the DC value, not yet its difference), 11-bit signed values.  w and h multiples of 8; flags: JPEGENC_HOST_PTRS (blocks) or JPEGENC_DEVICE_PTRS
+ * (enqueues on the context's stream). */
+int jpegenc_image_coeffs(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int h, ptrdiff_t stride, uint32_t flags,
+                         int16_t* coeffs_out);
+
 /* One image cut into n_stripes horizontal stripes of stripe_rows rows (a multiple of 8;
  * n_stripes*stripe_rows == h).  Every stripe is encoded exactly as jpeg_top would encode that
  * w x stripe_rows sub-image after rst -- the restart-interval view of a huge image.  Equivalent to

@@ -799,6 +799,43 @@ int jpegenc_encode_batch_noalloc(jpegenc_ctx* ctx, const uint8_t* rgb, int n_ima
     return workspace_used(ctx);
 }
 
+int jpegenc_image_coeffs(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int h, ptrdiff_t stride, uint32_t flags,
+                         int16_t* coeffs_out) {
+    if (!ctx || !rgb || !coeffs_out) return JPEGENC_E_BAD_ARG;
+    if (w <= 0 || h <= 0 || (w % 8) || (h % 8) || stride < ptrdiff_t(w) * 3) return JPEGENC_E_BAD_ARG;
+    const uint32_t mcu_w = uint32_t(w / 8);
+    const uint64_t n_mcu = uint64_t(mcu_w) * uint32_t(h / 8);
+    if (n_mcu > 0x7FFFFFFFull) return JPEGENC_E_UNSUPPORTED;
+    DevGuard guard(ctx->device);
+    HIPCHK(ctx, guard.err);
+    const int32_t* qmul = ctx->quant ? ctx->qmul.p : nullptr;
+    const bool wrap = (ctx->flags & 1u) != 0;
+    if (flags & JPEGENC_DEVICE_PTRS) {
+        HIPCHK(ctx, launch_coeffs(rgb, stride, mcu_w, uint32_t(n_mcu), wrap, qmul, coeffs_out, ctx->stream));
+        return JPEGENC_OK;
+    }
+    // host memory: staged through buffers of this call's own (a checking aid, not a hot path)
+    const size_t row = size_t(w) * 3, out_bytes = size_t(n_mcu) * 3 * 64 * sizeof(int16_t);
+    DevBuf<uint8_t> in;
+    DevBuf<int16_t> out;
+    hipError_t e = in.reserve(row * size_t(h));
+    if (e == hipSuccess) e = out.reserve(size_t(n_mcu) * 3 * 64);
+    if (e == hipSuccess)
+        e = hipMemcpy2DAsync(in.p, row, rgb, size_t(stride), row, size_t(h), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = launch_coeffs(in.p, int64_t(row), mcu_w, uint32_t(n_mcu), wrap, qmul, out.p, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(coeffs_out, out.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    in.release();
+    out.release();
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        ctx->last_error = "device memory exhausted: jpegenc_image_coeffs staging";
+        return JPEGENC_E_NOMEM;
+    }
+    HIPCHK(ctx, e);
+    return JPEGENC_OK;
+}
+
 int jpegenc_encode_rgb8(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int h, ptrdiff_t stride, uint32_t flags,
                         uint32_t* words_out, size_t cap_words, jpegenc_result* result) {
     return jpegenc_encode_batch(ctx, rgb, 1, w, h, stride, stride * ptrdiff_t(h), flags, words_out, cap_words, result);

@@ -127,6 +127,9 @@ hipError_t launch_stuff_image(const StuffParams& p, uint32_t n_images, hipStream
 hipError_t launch_pad_edges(const uint8_t* src, int64_t stride, int64_t image_stride, int w, int h, int n_images,
                             uint8_t* dst, hipStream_t s);
 
+hipError_t launch_coeffs(const uint8_t* rgb, int64_t stride, uint32_t mcu_w, uint32_t n_mcu, bool wrap,
+                         const int32_t* qmul, int16_t* out, hipStream_t s);
+
 // Host-side table construction (jpegenc_host.cpp).
 void build_htab(uint32_t out[kHtabEntries]);
 

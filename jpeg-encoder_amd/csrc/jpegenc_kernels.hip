@@ -1514,6 +1514,65 @@ hipError_t launch_pad_edges(const uint8_t* src, int64_t stride, int64_t image_st
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_coeffs: the coefficients as they enter the three Huffman coders (after colour conversion, the two DCT
+// passes, the quantisers and the wrapper transpose: yd_q_h.sv:120-135 and its Cb/Cr twins), for checking that
+// stage on its own.  Lane = MCU with the device functions of k_encode_chunks; out[mcu][component][k], k = the
+// position in the coder's reading order (zig-zag, cr_huff.sv:1053-1304).  Not on the hot path: byte loads,
+// strided 16-bit stores.
+// ------------------------------------------------------------------------------------------------
+template <bool WRAP>
+__global__ __launch_bounds__(64) void k_coeffs(const uint8_t* rgb, int64_t stride, uint32_t mcu_w, uint32_t n_mcu,
+                                               const int32_t* qmul, int16_t* out) {
+    const uint32_t b = blockIdx.x * 64u + threadIdx.x;
+    if (b >= n_mcu) return;
+    const uint32_t by = b / mcu_w, bx = b - by * mcu_w;
+    const uint8_t* src = rgb + (int64_t)by * 8 * stride + (int64_t)bx * 24;
+    uint32_t raw[48];
+    load_mcu<1>(src, stride, raw);
+#pragma unroll 1
+    for (int comp = 0; comp < 3; ++comp) {
+        const CompCoef cc = comp_coef(comp);
+        int x[64];
+        int pc[4][8];
+        if (comp == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int p0[4], p1[4];
+                colour_row<0>(raw, 2 * i, cc, p0);
+                colour_row<0>(raw, 2 * i + 1, cc, p1);
+                dct_row_pair<true>(p0, p1, i >= 2, pc[i]);
+            }
+            dct_cols_packed<true>(pc, x);
+            asm volatile("; luma dct done" ::: "memory");
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int p0[4], p1[4];
+                colour_row<WRAP ? 1 : 2>(raw, 2 * i, cc, p0);
+                colour_row<WRAP ? 1 : 2>(raw, 2 * i + 1, cc, p1);
+                dct_row_pair<false>(p0, p1, i >= 2, pc[i]);
+            }
+            dct_cols_packed<false>(pc, x);
+            asm volatile("; chroma dct done" ::: "memory");
+        }
+        int16_t* o = out + ((int64_t)b * 3 + comp) * 64;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) o[k] = (int16_t)(qmul ? quant(x[kZZ[k]], qmul[comp * 64 + kZZ[k]]) : x[kZZ[k]]);
+    }
+}
+
+hipError_t launch_coeffs(const uint8_t* rgb, int64_t stride, uint32_t mcu_w, uint32_t n_mcu, bool wrap,
+                         const int32_t* qmul, int16_t* out, hipStream_t s) {
+    (void)hipGetLastError();
+    const dim3 grid((n_mcu + 63u) / 64u);
+    if (wrap)
+        hipLaunchKernelGGL(k_coeffs<true>, grid, dim3(64), 0, s, rgb, stride, mcu_w, n_mcu, qmul, out);
+    else
+        hipLaunchKernelGGL(k_coeffs<false>, grid, dim3(64), 0, s, rgb, stride, mcu_w, n_mcu, qmul, out);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Workspace of jpegenc_encode_batch_noalloc: one array per device, part of the code object, held for as long
 // as the library stays loaded.  On the host the array's name is only a handle for hipGetSymbolAddress; what
 // kernels, memsets and copies need is the device address that static_workspace() looks up.

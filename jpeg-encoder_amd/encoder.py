@@ -26,7 +26,7 @@ N_KERNELS = 5
 ABI_SYMBOLS = [
     "jpegenc_default_config", "jpegenc_create", "jpegenc_destroy", "jpegenc_set_stream", "jpegenc_synchronize",
     "jpegenc_max_words", "jpegenc_encode_rgb8", "jpegenc_encode_batch", "jpegenc_encode_batch_noalloc",
-    "jpegenc_encode_stripes", "jpegenc_reset",
+    "jpegenc_encode_stripes", "jpegenc_image_coeffs", "jpegenc_reset",
     "jpegenc_push_pixel", "jpegenc_push_pixels", "jpegenc_end_of_file", "jpegenc_read_words",
     "jpegenc_words_to_bytes", "jpegenc_set_profiling", "jpegenc_kernel_times", "jpegenc_kernel_name",
     "jpegenc_set_workspace_limit", "jpegenc_set_region_mode", "jpegenc_region_stats", "jpegenc_set_pipeline", "jpegenc_reserve", "jpegenc_segment_encode", "jpegenc_segment_count",
@@ -102,6 +102,7 @@ def load_library(path=None):
     L.jpegenc_set_region_mode.argtypes = [vp, i32]
     L.jpegenc_set_pipeline.argtypes = [vp, i32]
     L.jpegenc_region_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.jpegenc_image_coeffs.argtypes = [vp, vp, i32, i32, C.c_ssize_t, u32, vp]
     u64 = C.c_uint64
     L.jpegenc_segment_encode.argtypes = [vp, vp, i32, i32, C.c_ssize_t, u32, C.POINTER(u64), C.POINTER(u32)]
     L.jpegenc_segment_count.argtypes = [vp, u64, u32, C.POINTER(u64)]
@@ -248,6 +249,15 @@ class JpegTop:
                                                     words.ctypes.data, cap, res.ctypes.data))
         return [words[i, :int(res[i]["n_full_words"]) + (1 if res[i]["tail_bits"] else 0)].copy()
                 for i in range(n_stripes)], res
+
+    def image_coeffs(self, rgb):
+        """The coefficients as they enter the Huffman coders: int16 array [blocks, 3, 64] (block row-major,
+        component Y/Cb/Cr, position in the coder's zig-zag reading order).  rgb: uint8 [h, w, 3] on the host."""
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        h, w, _ = rgb.shape
+        out = np.zeros(((h // 8) * (w // 8), 3, 64), dtype=np.int16)
+        self._check(self.lib.jpegenc_image_coeffs(self._ctx, rgb.ctypes.data, w, h, w * 3, HOST_PTRS, out.ctypes.data))
+        return out
 
     # -- raster API (device memory, asynchronous on the context's stream) -------------------
     def encode_batch_device(self, rgb_ptr, n, w, h, stride, image_stride, words_ptr, cap_words, results_ptr):

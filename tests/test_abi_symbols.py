@@ -75,6 +75,8 @@ def test_bad_arguments_are_rejected_without_touching_the_gpu():
     assert lib.jpegenc_encode_batch_noalloc(null, None, 1, 8, 8, 24, 192, None, 16, None) == pkg.E_BAD_ARG
     assert lib.jpegenc_encode_batch(null, None, 1, 8, 8, 24, 192, 0, None, 16, None) == pkg.E_BAD_ARG
     assert lib.jpegenc_segment_count(null, 0, 0, None) == pkg.E_BAD_ARG
+    assert lib.jpegenc_image_coeffs(null, None, 8, 8, 24, 0, None) == pkg.E_BAD_ARG
+    assert lib.jpegenc_region_stats(null, None) == pkg.E_BAD_ARG
     assert lib.jpegenc_strerror(pkg.E_LIMIT) == b"call exceeds the static workspace of jpegenc_encode_batch_noalloc"
     assert lib.jpegenc_strerror(pkg.E_NOMEM) == b"out of memory"
 

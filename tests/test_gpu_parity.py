@@ -181,6 +181,58 @@ def test_quirk_switches_and_quant_tables():
     assert differ(3, 6), "quant_index_order changed nothing"
 
 
+def test_coefficients_before_the_entropy_coders():
+    """The stage in front of the Huffman coders on its own (jpegenc_image_coeffs against the oracle's
+    ref_image_coeffs): colour conversion, both DCT passes, quantisers and transpose, value for value -- natural
+    content, noise, the colours that wrap or clamp, flat extremes; default and non-default tables in both index
+    orders, both settings of the colour-rounder switch.  A stream mismatch can then be placed before or after
+    this point."""
+    pkg = load_pkg()
+    rng = np.random.default_rng(77)
+    nat = natural_like(72, 136, 8)
+    nat[:8, :8] = (0, 0, 255)     # pure blue: Cb reaches 256
+    nat[8:16, :8] = (255, 0, 0)   # pure red: Cr reaches 256
+    nat[16:24, :8] = 255
+    nat[24:32, :8] = 0
+    noise = rng.integers(0, 256, (40, 264, 3), dtype=np.uint8)
+    checker = np.zeros((16, 16, 3), np.uint8)
+    checker[::2, 1::2] = 255
+    checker[1::2, ::2] = 255
+    qt = [rng.integers(1, 64, 64), rng.integers(1, 100, 64), np.full(64, 16)]
+    qt[1][9] = 0
+    cases = [dict(), dict(rgb_wrap=False), dict(qtabs=qt), dict(qtabs=qt, quant_index_order=1),
+             dict(qtabs=qt, rgb_wrap=False)]
+    seen = {}
+    for k, kw in enumerate(cases):
+        cfg = O.default_config(qtabs=kw.get("qtabs"), rgb_wrap=kw.get("rgb_wrap", True),
+                               quant_index_order=kw.get("quant_index_order", 0))
+        with pkg.JpegTop(**kw) as e:
+            for name, img in (("nat", nat), ("noise", noise), ("checker", checker)):
+                got = e.image_coeffs(img)
+                want = O.image_coeffs(img, cfg)
+                assert got.shape == want.shape
+                if not np.array_equal(got, want):
+                    blk, comp, idx = (int(v[0]) for v in np.nonzero(got != want))
+                    raise AssertionError("%s case %d: block %d component %d index %d: got %d want %d" % (
+                        name, k, blk, comp, idx, got[blk, comp, idx], want[blk, comp, idx]))
+                seen[k, name] = got
+    assert not np.array_equal(seen[0, "nat"], seen[1, "nat"]), "rgb_wrap changed no coefficient"
+    assert not np.array_equal(seen[2, "noise"], seen[3, "noise"]), "quant_index_order changed no coefficient"
+    # device pointers: the same values, enqueued on the context's stream
+    torch = pytest.importorskip("torch")
+    with pkg.JpegTop(stream=torch.cuda.current_stream().cuda_stream) as e:
+        d_img = torch.from_numpy(noise).cuda()
+        d_out = torch.zeros((5 * 33, 3, 64), dtype=torch.int16, device="cuda")
+        rc = e.lib.jpegenc_image_coeffs(e._ctx, d_img.data_ptr(), 264, 40, 264 * 3, pkg.DEVICE_PTRS,
+                                        d_out.data_ptr())
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(d_out.cpu().numpy(), seen[0, "noise"])
+        # sizes that are not multiples of 8 are refused
+        assert e.lib.jpegenc_image_coeffs(e._ctx, d_img.data_ptr(), 260, 40, 264 * 3, pkg.DEVICE_PTRS,
+                                          d_out.data_ptr()) == pkg.E_BAD_ARG
+
+
 def test_batch_and_stripes(enc):
     rng = np.random.default_rng(21)
     imgs = np.stack([natural_like(72, 136, 30 + i) for i in range(5)] +
