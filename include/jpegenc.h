@@ -234,7 +234,8 @@ int jpegenc_set_pipeline(jpegenc_ctx* ctx, int mode);
  * a block of uniform noise needs on average) leave room for eight wavefronts and cost 15 % where small ones
  * suffice.  AUTO (default): the kernel counts, in every launch, the groups with a block too long for a small
  * and for a large region, and the context uses for the next launches whichever size those counts make
- * cheaper (large from about 3 to 4 % of the groups too long for small regions on). */
+ * cheaper (large from about 3 to 4 % of the groups too long for small regions on, at once; back to small
+ * after four launches in a row whose counts favour it). */
 #define JPEGENC_REGIONS_AUTO 0
 #define JPEGENC_REGIONS_SMALL 1
 #define JPEGENC_REGIONS_LARGE 2

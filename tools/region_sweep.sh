@@ -1,4 +1,8 @@
-for P in 3.7 4.0 4.3; do for R in small large auto; do
+#!/bin/bash
+# Encode-kernel time and overflow fractions over content detail with small, large and automatically chosen LDS
+# regions (run inside gpurun).  usage: region_sweep.sh [P ...]   (default 3.5 3.7 4.0 4.3 5.0 7.0)
+Ps=${@:-3.5 3.7 4.0 4.3 5.0 7.0}
+for P in $Ps; do for R in small large auto; do
 timeout -k 10 200 python -u bench.py --steps 6 --warmup 2 --no-cpu --persistence $P --regions $R > gpurun_out/sw.log 2>&1 || { tail -5 gpurun_out/sw.log; exit 1; }
 python - $P $R <<'PY'
 import json, sys
