@@ -222,9 +222,13 @@ int jpegenc_set_workspace_limit(jpegenc_ctx* ctx, size_t bytes);
  * kernel launch -- every group's wavefront waits for the bit and 0xFF counts of the groups before it, then
  * stuffs and writes its own part of the stream (a wavefront that waits in vain for a tenth of a second gives
  * up and the image's status becomes JPEGENC_E_HIP); everything else runs as separate kernels (encode, prefix
- * sums, 0xFF count, stuff + write).  SPLIT: always the separate kernels. */
+ * sums, 0xFF count, stuff + write).  Within the single launch a wavefront lane codes one 8x8 block of Y, Cb and
+ * Cr (groups of 64 blocks), or, for calls of at most 2048 x 21 blocks (one 1080p frame), one component of a
+ * block (groups of 21 blocks: three times the wavefronts, a third of the work each).  SPLIT: always the
+ * separate kernels.  SINGLE_MCU: as AUTO without the one-component-per-lane form. */
 #define JPEGENC_PIPELINE_AUTO 0
 #define JPEGENC_PIPELINE_SPLIT 1
+#define JPEGENC_PIPELINE_SINGLE_MCU 2
 int jpegenc_set_pipeline(jpegenc_ctx* ctx, int mode);
 
 /* How the encode kernel sizes the per-block staging regions in LDS.  No counterpart in jpeg_top and no

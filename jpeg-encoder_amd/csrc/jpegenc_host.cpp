@@ -394,18 +394,27 @@ int run_group(jpegenc_ctx* ctx, const Workspace& ws, bool timed, const Plan& pl,
     ep.qmul = ctx->quant ? ctx->qmul.p : nullptr;
     ep.state = nullptr;
     ep.generation = 0;
+    ep.lanes_per_mcu = 1;
     ep.words_out = words;
     ep.out_stride = cap_words;
     ep.cap_words = cap_words;
     ep.results = results;
     // A frame or a few (every chunk resident at once), common kernel variant: one launch does it all -- each
     // chunk's wave waits for the counts of the chunks before it, then stuffs and writes its own stream.
-    if (timed && ctx->pipeline == JPEGENC_PIPELINE_AUTO && uint64_t(n) * cpi <= kSingleLaunchMaxChunks && !ctx->quant &&
+    if (timed && ctx->pipeline != JPEGENC_PIPELINE_SPLIT && uint64_t(n) * cpi <= kSingleLaunchMaxChunks && !ctx->quant &&
         align >= 8) {
         ep.stats = nullptr;
         ep.large_regions = 1;
         ep.state = ctx->state.p;
         ep.generation = next_generation();
+        // about a frame of 1080p or less: a lane per component block, chunks of 21 MCUs -- three times the waves
+        // with a third of the work each, on a GPU that such a call leaves mostly idle (the workspace holds slots
+        // for these chunks too: encode_device has seen to it)
+        const uint32_t cpi_wide = (pl.n_mcu + kWideChunkMcus - 1) / kWideChunkMcus;
+        if (ctx->pipeline == JPEGENC_PIPELINE_AUTO && uint64_t(n) * cpi_wide <= kSingleLaunchMaxChunks) {
+            ep.cpi = cpi_wide;
+            ep.lanes_per_mcu = 3;
+        }
         ProfScope ps(ctx, K_ENCODE);
         HIPCHK(ctx, launch_encode(ep, n, align, ctx->stream));
         return JPEGENC_OK;
@@ -481,6 +490,10 @@ int encode_device(jpegenc_ctx* ctx, const uint8_t* rgb, int n_images, int w, int
     ctx->seg_ready = ctx->seg_counted = false;  // whatever a segment call left in the workspace is gone
     rc = reserve_for_plan(ctx, &pl);
     if (rc != JPEGENC_OK) return rc;
+    {   // the single-launch form of the smallest calls cuts an image into more chunks (run_group)
+        const uint64_t wide = uint64_t(n_images) * ((pl.n_mcu + kWideChunkMcus - 1) / kWideChunkMcus);
+        if (wide <= kSingleLaunchMaxChunks) MEMCHK(ctx, reserve_workspace(ctx, size_t(wide)));
+    }
     const Workspace ws = ctx_workspace(ctx);
     const int align = pointer_align(rgb, stride, image_stride, n_images, h);
     for (int first = 0; first < n_images; first += int(pl.sub)) {
@@ -908,6 +921,7 @@ int jpegenc_segment_encode(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int rows
     // the block row above must be as aligned as the segment's own rows: the stride takes care of that
     ep.state = nullptr;
     ep.generation = 0;
+    ep.lanes_per_mcu = 1;
     ep.words_out = nullptr;
     ep.out_stride = ep.cap_words = 0;
     ep.results = nullptr;
@@ -1132,7 +1146,7 @@ const char* jpegenc_kernel_name(int index) {
 }
 
 int jpegenc_set_pipeline(jpegenc_ctx* ctx, int mode) {
-    if (!ctx || (mode != JPEGENC_PIPELINE_AUTO && mode != JPEGENC_PIPELINE_SPLIT)) return JPEGENC_E_BAD_ARG;
+    if (!ctx || mode < JPEGENC_PIPELINE_AUTO || mode > JPEGENC_PIPELINE_SINGLE_MCU) return JPEGENC_E_BAD_ARG;
     ctx->pipeline = mode;
     return JPEGENC_OK;
 }

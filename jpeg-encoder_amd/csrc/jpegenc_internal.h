@@ -53,7 +53,7 @@ struct EncodeParams {
     int64_t image_stride;  // bytes between images
     uint32_t mcu_w;        // MCUs per block row (w / 8)
     uint32_t n_mcu;        // MCUs per image
-    uint32_t cpi;          // chunks per image = ceil(n_mcu / 64)
+    uint32_t cpi;          // chunks per image = ceil(n_mcu / 64), or ceil(n_mcu / 21) when lanes_per_mcu == 3
     uint32_t n_images;     // images of this launch (set by launch_encode)
     uint32_t flags;        // bit 0: rgb wrap quirk, bit 1: cb 6'd64 quirk, bit 2: the images continue a
                            // stream: the DC predictors of their first MCU come from the block row above
@@ -72,6 +72,7 @@ struct EncodeParams {
     // words of earlier launches read as "not there yet", so the array needs no clearing).
     uint64_t* state;
     uint32_t generation;
+    uint32_t lanes_per_mcu;   // 1, or 3 (single-launch form only): a lane per component block, chunks of 21 MCUs
     uint32_t* words_out;      // as in StuffParams
     uint64_t out_stride;
     uint64_t cap_words;
@@ -79,6 +80,7 @@ struct EncodeParams {
 };
 // Largest launch that takes the single-launch form: all its chunks are resident at once (256 CUs x 8 workgroups).
 constexpr uint32_t kSingleLaunchMaxChunks = 2048;
+constexpr uint32_t kWideChunkMcus = 21;  // MCUs per chunk with a lane per component block
 constexpr int kEncodeStatsWords = 16 * 16 + 16;
 
 struct ScanParams {

@@ -162,6 +162,12 @@ __device__ __forceinline__ int dot2(int a, int c, int acc) {
     asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(c), "v"(acc));
     return r;
 }
+// the same with the coefficient pair in a vector register (a value per lane)
+__device__ __forceinline__ int dot2v(int a, int c, int acc) {
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(c), "v"(acc));
+    return r;
+}
 __host__ __device__ constexpr int cpair(int lo, int hi) { return (int)(((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16)); }
 
 // Inputs as pairs p01 = (x0,x1), p23 = (x2,x3), p76 = (x7,x6), p54 = (x5,x4); a[k] = sum + bias.
@@ -208,6 +214,25 @@ __device__ __forceinline__ void dct_row_pair(const int (&p0)[4], const int (&p1)
 #pragma unroll
     for (int k = 0; k < 8; ++k)
         col[k] = lower_half ? shift_pack(a1[k], a0[k], DctK<LUMA>::sh1) : shift_pack(a0[k], a1[k], DctK<LUMA>::sh1);
+}
+
+// The two passes with the rounding positions as values (one component per lane: luma and chroma lanes side by side).
+__device__ __forceinline__ void dct_row_pair_v(const int (&p0)[4], const int (&p1)[4], bool lower_half, int b1, int sh1,
+                                               int (&col)[8]) {
+    int a0[8], a1[8];
+    dct8p_acc(p0[0], p0[1], p0[2], p0[3], b1 - JPEGENC_DCT_LEVEL_SHIFT, b1, a0);
+    dct8p_acc(p1[0], p1[1], p1[2], p1[3], b1 - JPEGENC_DCT_LEVEL_SHIFT, b1, a1);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) col[k] = lower_half ? shift_pack(a1[k], a0[k], sh1) : shift_pack(a0[k], a1[k], sh1);
+}
+__device__ __forceinline__ void dct_cols_packed_v(const int (&pc)[4][8], int b2, int sh2, int (&x)[64]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        int y[8];
+        dct8p(pc[0][k], pc[1][k], pc[3][k], pc[2][k], b2, b2, sh2, y);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j * 8 + k] = y[j];
+    }
 }
 
 // Pass 2: column k from its four row pairs -> x[j*8+k], j = vertical frequency.
@@ -467,6 +492,24 @@ __device__ __forceinline__ void colour_row(const uint32_t (&raw)[48], int r, con
         const uint32_t sel = 0x0C000C00u | (uint32_t)b | ((uint32_t)(b == 3 ? 4 : b + 1) << 16);
         const int rg = (int)__builtin_amdgcn_perm(hi, lo, sel);
         s[q] = dot2(rg, crg, cc.k0) + __mul24(cc.cb, (int)raw_byte(raw, r, j + 2));
+    }
+    p[0] = colour_pair<MODE>(s[0], s[1]);
+    p[1] = colour_pair<MODE>(s[2], s[3]);
+    p[2] = colour_pair<MODE>(s[7], s[6]);
+    p[3] = colour_pair<MODE>(s[5], s[4]);
+}
+
+// The same with the component's coefficients as values per lane (crg = the R and G coefficients as a 16-bit pair).
+template <int MODE>
+__device__ __forceinline__ void colour_row_v(const uint32_t (&raw)[48], int r, int k0, int crg, int cb, int (&p)[4]) {
+    int s[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int j = 3 * q, d = j >> 2, b = j & 3;
+        const uint32_t lo = raw[r * 6 + d], hi = raw[r * 6 + (b == 3 ? d + 1 : d)];
+        const uint32_t sel = 0x0C000C00u | (uint32_t)b | ((uint32_t)(b == 3 ? 4 : b + 1) << 16);
+        const int rg = (int)__builtin_amdgcn_perm(hi, lo, sel);
+        s[q] = dot2v(rg, crg, k0) + __mul24(cb, (int)raw_byte(raw, r, j + 2));
     }
     p[0] = colour_pair<MODE>(s[0], s[1]);
     p[1] = colour_pair<MODE>(s[2], s[3]);
@@ -892,8 +935,13 @@ __device__ __forceinline__ uint32_t fit_range_end(uint32_t need_incl, uint32_t l
     return lo + (uint32_t)__popcll(fits);
 }
 
-template <int ALIGN, bool QUANT, bool WRAP, int REGION, bool FUSED, int WAVES>
+// LPM (lanes per MCU) = 3, single-launch form of calls of at most 2048 x 21 MCUs (one 1080p frame): a lane codes one
+// component block, lane = 3 * MCU + component, 21 MCUs per chunk -- a third of the work per wave and three times
+// the waves, for calls that leave most of the GPU idle otherwise.  The 63 strings concatenate in lane order as ever.
+template <int ALIGN, bool QUANT, bool WRAP, int REGION, bool FUSED, int WAVES, int LPM = 1>
 __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_encode_chunks(EncodeParams p) {
+    static_assert(LPM == 1 || (LPM == 3 && FUSED && !QUANT && ALIGN == 8), "one lane per block exists for the single-launch form only");
+    constexpr int kMcus = LPM == 3 ? 21 : kChunkMcus;  // MCUs per chunk
     constexpr int kRegionWords = REGION;
     constexpr int kOwnWords = kRegionWords - 1;  // first pass: REGION - 2 usable words and one zero word behind them
     constexpr int kOwnRegs = (kOwnWords + 7) & ~7;  // the in-register concatenation works in blocks of 8 words
@@ -954,13 +1002,16 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
     // MCU coordinates: one division for the chunk's first MCU (wave-uniform); a lane's own follow from its
     // offset with at most one step to the next block row when the image is at least 64 MCUs wide.  Lanes
     // behind the image's last MCU read that last MCU.
-    const uint32_t b0 = c * kChunkMcus;
+    const uint32_t b0 = c * kMcus;
     const uint32_t by0 = b0 / p.mcu_w, bx0 = b0 - by0 * p.mcu_w;
-    const uint32_t b = b0 + lane;
-    const bool valid = b < p.n_mcu;
-    const uint32_t off = min((uint32_t)lane, p.n_mcu - 1u - b0);
+    // this lane's MCU within the chunk and (LPM == 3) its component; lane 63 has none there
+    const uint32_t ml = LPM == 3 ? min((uint32_t)lane / 3u, (uint32_t)kMcus - 1u) : (uint32_t)lane;
+    [[maybe_unused]] const uint32_t lcomp = LPM == 3 ? ((uint32_t)lane - 3u * ((uint32_t)lane / 3u)) : 0u;
+    const uint32_t b = b0 + ml;
+    const bool valid = b < p.n_mcu && (LPM == 1 || lane < 3 * kMcus);
+    const uint32_t off = min(ml, p.n_mcu - 1u - b0);
     uint32_t by, bx;
-    if (p.mcu_w >= (uint32_t)kChunkMcus) {
+    if (p.mcu_w >= (uint32_t)kMcus) {
         const uint32_t x = bx0 + off;
         const uint32_t wrap = (uint32_t)((int32_t)(p.mcu_w - 1u - x) >> 31);  // all ones when x >= mcu_w
         by = by0 - wrap;
@@ -1036,8 +1087,40 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
         bw.win = 0;
         bw.T = base * 32u;
 
+        if constexpr (LPM == 3) {
+            // one block per lane: the component's constants are values of the lane
+            const bool luma = lcomp == 0;
+            const int k0 = luma ? 8192 : (JPEGENC_C_OFFSET + 8192);
+            const int cr = luma ? JPEGENC_Y_R : (lcomp == 1) ? -JPEGENC_CB_R : JPEGENC_CR_R;
+            const int cg = luma ? JPEGENC_Y_G : (lcomp == 1) ? -JPEGENC_CB_G : -JPEGENC_CR_G;
+            const int cb = luma ? JPEGENC_Y_B : (lcomp == 1) ? JPEGENC_CB_B : -JPEGENC_CR_B;
+            const int crg = (int)(((uint32_t)cr & 0xFFFFu) | ((uint32_t)cg << 16));
+            const int sh1 = luma ? 12 : 14, sh2 = luma ? 16 : 14;
+            const int b1 = 1 << (sh1 - 1), b2 = 1 << (sh2 - 1);
+            int x[64];
+            uint32_t raw[48];
+            load_mcu_buf<true>(img_rsrc, lane_off, (int32_t)p.stride, raw);
+            int pc[4][8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int p0[4], p1[4];
+                // (luma never reaches 256, so the chroma form of the rounder's last step serves every lane)
+                colour_row_v<WRAP ? 1 : 2>(raw, 2 * i, k0, crg, cb, p0);
+                colour_row_v<WRAP ? 1 : 2>(raw, 2 * i + 1, k0, crg, cb, p1);
+                dct_row_pair_v(p0, p1, i >= 2, b1, sh1, pc[i]);
+            }
+            dct_cols_packed_v(pc, b2, sh2, x);
+            // DC of the same component one MCU earlier = three lanes down; the first MCU takes the halo's
+            const int h = luma ? halo[0] : (lcomp == 1) ? halo[1] : halo[2];
+            const int before = __builtin_amdgcn_ds_bpermute((lane - 3) << 2, x[0]);
+            const int pred = lane < 3 ? h : before;
+            if (!fit)
+                encode_block<false, QUANT>(x, pred, lcomp == 1 && cb_quirk, htab, hlen, flat, bw);
+            else
+                encode_block<true, QUANT>(x, pred, lcomp == 1 && cb_quirk, htab, hlen, flat, bw);
+        }
 #pragma unroll 1
-        for (int comp = 0; comp < 3; ++comp) {
+        for (int comp = 0; LPM == 1 && comp < 3; ++comp) {
             const CompCoef cc = comp_coef(comp);
             int x[64];
             // The MCU's 192 bytes are fetched again for every component (mostly from L2): holding them in 48
@@ -1593,14 +1676,14 @@ hipError_t static_workspace(void** ptr) {
 // (9 % faster), while the variants for the all-ones tables lose 5 % under it and keep the default strategy.
 // (Every launcher first takes any error an earlier, unrelated HIP call has left pending: what it returns is
 // then the outcome of its own launch.)
-template <int ALIGN, bool QUANT, int REGION, bool FUSED = false, int WAVES = 1>
+template <int ALIGN, bool QUANT, int REGION, bool FUSED = false, int WAVES = 1, int LPM = 1>
 static hipError_t launch_encode_b(const EncodeParams& p, dim3 grid, hipStream_t s) {
     (void)hipGetLastError();
     grid.x = (grid.x + WAVES - 1) / WAVES;  // WAVES chunks per workgroup
     if (p.flags & 1u)
-        hipLaunchKernelGGL((k_encode_chunks<ALIGN, QUANT, true, REGION, FUSED, WAVES>), grid, dim3(64 * WAVES), 0, s, p);
+        hipLaunchKernelGGL((k_encode_chunks<ALIGN, QUANT, true, REGION, FUSED, WAVES, LPM>), grid, dim3(64 * WAVES), 0, s, p);
     else
-        hipLaunchKernelGGL((k_encode_chunks<ALIGN, QUANT, false, REGION, FUSED, WAVES>), grid, dim3(64 * WAVES), 0, s, p);
+        hipLaunchKernelGGL((k_encode_chunks<ALIGN, QUANT, false, REGION, FUSED, WAVES, LPM>), grid, dim3(64 * WAVES), 0, s, p);
     return hipGetLastError();
 }
 
@@ -1626,6 +1709,7 @@ hipError_t launch_encode(const EncodeParams& p_in, uint32_t n_images, int align,
     if (p.state) {
         // single-launch form: only the common variant (a launch this small leaves most of the LDS unused anyway)
         if (p.qmul || align < 8 || chunks > kSingleLaunchMaxChunks) return hipErrorInvalidValue;
+        if (p.lanes_per_mcu == 3) return launch_encode_b<8, false, kRegionFused, true, 1, 3>(p, grid, s);
         return launch_encode_b<8, false, kRegionFused, true>(p, grid, s);
     }
     if (p.qmul) return launch_encode_quant(p, grid, align, s);

@@ -188,7 +188,7 @@ class JpegTop:
         """LDS staging regions of the encode kernel: REGIONS_AUTO (default), REGIONS_SMALL, REGIONS_LARGE; speed only."""
         self._check(self.lib.jpegenc_set_region_mode(self._ctx, int(mode)))
 
-    PIPELINE_AUTO, PIPELINE_SPLIT = 0, 1
+    PIPELINE_AUTO, PIPELINE_SPLIT, PIPELINE_SINGLE_MCU = 0, 1, 2
 
     def set_pipeline(self, mode):
         """PIPELINE_AUTO (default): small calls run as one kernel launch; PIPELINE_SPLIT: always separate kernels."""

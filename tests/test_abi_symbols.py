@@ -90,8 +90,8 @@ def test_header_constants_match_the_python_mirror():
     assert int(defs["JPEGENC_N_KERNELS"]) == 5
     assert (int(defs["JPEGENC_E_LIMIT"]), int(defs["JPEGENC_E_NOMEM"]), int(defs["JPEGENC_E_STATE"])) == \
            (pkg.E_LIMIT, pkg.E_NOMEM, pkg.E_STATE)
-    assert (int(defs["JPEGENC_PIPELINE_AUTO"]), int(defs["JPEGENC_PIPELINE_SPLIT"])) == \
-           (pkg.JpegTop.PIPELINE_AUTO, pkg.JpegTop.PIPELINE_SPLIT)
+    assert (int(defs["JPEGENC_PIPELINE_AUTO"]), int(defs["JPEGENC_PIPELINE_SPLIT"]), int(defs["JPEGENC_PIPELINE_SINGLE_MCU"])) == \
+           (pkg.JpegTop.PIPELINE_AUTO, pkg.JpegTop.PIPELINE_SPLIT, pkg.JpegTop.PIPELINE_SINGLE_MCU)
     assert (int(defs["JPEGENC_REGIONS_AUTO"]), int(defs["JPEGENC_REGIONS_SMALL"]), int(defs["JPEGENC_REGIONS_LARGE"])) == \
            (pkg.JpegTop.REGIONS_AUTO, pkg.JpegTop.REGIONS_SMALL, pkg.JpegTop.REGIONS_LARGE)
     assert (int(defs["JPEGENC_DEVICE_PTRS"]), int(defs["JPEGENC_PAD_EDGES"]), int(defs["JPEGENC_SEG_CONTINUES"])) == \

@@ -13,14 +13,17 @@ from conftest import load_pkg, natural_like
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["auto", "split"])
+@pytest.fixture(scope="module", params=["auto", "single_mcu", "split"])
 def enc(request):
-    """Small calls run as one kernel launch by default and as separate kernels on request: both forms take every
-    test that uses this encoder."""
+    """Small calls run as one kernel launch by default (the smallest with a lane per component block, the others
+    with a lane per block of all three) and as separate kernels on request: all three forms take every test that
+    uses this encoder."""
     pkg = load_pkg()
     e = pkg.JpegTop()
     if request.param == "split":
         e.set_pipeline(e.PIPELINE_SPLIT)
+    if request.param == "single_mcu":
+        e.set_pipeline(e.PIPELINE_SINGLE_MCU)
     yield e
     e.close()
 

@@ -56,7 +56,7 @@ def main():
         cfg = O.default_config(qtabs=kw.get("qtabs"), rgb_wrap=kw["rgb_wrap"], cb_6d64=kw["cb_6d64"])
         with pkg.JpegTop(**kw) as e:
             # launch structure and LDS region size change the speed only: any combination must give the same words
-            e.set_pipeline(int(rng.integers(0, 2)))
+            e.set_pipeline(int(rng.integers(0, 3)))
             e.set_region_mode(int(rng.integers(0, 3)))
             for _ in range(4):
                 h, w = 8 * int(rng.integers(1, 40)), 8 * int(rng.integers(1, 70))
