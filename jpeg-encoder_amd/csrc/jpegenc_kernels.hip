@@ -20,6 +20,8 @@
 //               1053-1304 (zig-zag), 1317-1486 (sizes), 1553-2082 (tables); y_huff.sv:184-193; cb_huff.sv:230-243
 //   interleave  rtl/5_fifo/fifo_out.sv:195-197, 222-243, 257-266
 //   stuffing    rtl/5_fifo/ff_checker.sv:96-179, 265-360
+#include <type_traits>
+
 #include "jpegenc_internal.h"
 #include "jpegenc_tables.h"
 
@@ -308,10 +310,75 @@ __device__ __forceinline__ uint32_t amp_bits(int t, uint32_t size) {
     return __builtin_amdgcn_ubfe((uint32_t)t, 0u, size);
 }
 
-template <bool GUARD, bool SKIP>
+// ---- several symbols per append --------------------------------------------------------------------
+// An append costs six instructions and an LDS store whatever it carries, so consecutive symbols are first
+// joined in a register, (earlier << length of later) | later, pairs into fours into eights, and go out in one
+// append when no lane's joined string exceeds 32 bits (then at most one word completes, as bw_emit needs).
+// Joining costs 2.5 instructions per symbol.  Whether a group fits is one compare and a wave-uniform branch;
+// a group that does not fit in some lane goes out as its two halves, each tried the same way, down to
+// single symbols.  Which positions are tried in groups of which size is fixed (see encode_block): the low
+// frequencies of photographic content hold the long codes.
+struct AcSym {
+    uint32_t h, a, l;  // code << size, amplitude bits, code length + size (all 0: nothing to emit)
+};
+struct Joined {
+    uint32_t m, l;  // bits and their number (m is only meaningful while l <= 32)
+};
+// x << n for n <= 32 where n == 32 only meets x == 0 (an empty left part): the hardware takes n modulo 32
+__device__ __forceinline__ uint32_t shl_mod(uint32_t x, uint32_t n) { return x << (n & 31u); }
+__device__ __forceinline__ Joined join_syms(const AcSym& x, const AcSym& y) {
+    return {or3_fast(shl_mod(x.h | x.a, y.l), y.h, y.a), x.l + y.l};
+}
+__device__ __forceinline__ Joined join(const Joined& x, const Joined& y) { return {shl_mod(x.m, y.l) | y.m, x.l + y.l}; }
+__device__ __forceinline__ bool fits_all(const Joined& j) { return !__any((int)(j.l > 32u)); }
+
+template <bool GUARD>
+__device__ __forceinline__ void emit_pair(BitWriter& bw, const AcSym& s0, const AcSym& s1, const Joined& p, uint32_t* priv) {
+    if (fits_all(p)) {
+        bw_emit<GUARD>(bw, p.m, 0u, p.l, priv);
+    } else {
+        bw_emit<GUARD>(bw, s0.h, s0.a, s0.l, priv);
+        bw_emit<GUARD>(bw, s1.h, s1.a, s1.l, priv);
+    }
+}
+template <bool GUARD>
+__device__ __forceinline__ void emit_quad(BitWriter& bw, const AcSym* s, const Joined& p0, const Joined& p1, const Joined& q,
+                                          uint32_t* priv) {
+    if (fits_all(q)) {
+        bw_emit<GUARD>(bw, q.m, 0u, q.l, priv);
+    } else {
+        emit_pair<GUARD>(bw, s[0], s[1], p0, priv);
+        emit_pair<GUARD>(bw, s[2], s[3], p1, priv);
+    }
+}
+// N = 2, 4 or 8 symbols, tried as one group first
+template <bool GUARD, int N>
+__device__ __forceinline__ void emit_group(BitWriter& bw, const AcSym (&s)[N], uint32_t* priv) {
+    static_assert(N == 2 || N == 4 || N == 8, "pairs, fours, eights");
+    Joined p[N / 2];
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) p[i] = join_syms(s[2 * i], s[2 * i + 1]);
+    if constexpr (N == 2) {
+        emit_pair<GUARD>(bw, s[0], s[1], p[0], priv);
+    } else if constexpr (N == 4) {
+        emit_quad<GUARD>(bw, s, p[0], p[1], join(p[0], p[1]), priv);
+    } else {
+        const Joined q0 = join(p[0], p[1]), q1 = join(p[2], p[3]);
+        const Joined o = join(q0, q1);
+        if (fits_all(o)) {
+            bw_emit<GUARD>(bw, o.m, 0u, o.l, priv);
+        } else {
+            emit_quad<GUARD>(bw, s, p[0], p[1], q0, priv);
+            emit_quad<GUARD>(bw, s + 4, p[2], p[3], q1, priv);
+        }
+    }
+}
+
+template <bool GUARD, bool SKIP, bool MERGE = false>
 __device__ __forceinline__ void encode_block(const int (&blk)[64], int dc_pred, bool cb_eob_quirk,
                                              const uint32_t* htab, const uint8_t* hlen, uint32_t* priv,
                                              BitWriter& bw) {
+    static_assert(!(MERGE && SKIP), "the position-skipping loop appends symbol by symbol");
     {   // DC difference, 12 bit (cr_huff.sv:1317): |d| <= 2047 for 11-bit inputs, no wrap possible
         const int t = amp_src(blk[0] - dc_pred);
         const uint32_t size = mag_bits(lead_bits(t));
@@ -343,6 +410,43 @@ __device__ __forceinline__ void encode_block(const int (&blk)[64], int dc_pred, 
     uint32_t r5 = 0;  // run << 5
     uint32_t run_mask = 0x1E0u;
     asm volatile("" : "+v"(run_mask));  // kept in a vector register: a scalar operand would halve the issue rate
+    if constexpr (MERGE) {
+        // table entry and amplitude of the coefficient at zig-zag position k; moves the run counter
+        auto sym_at = [&](int k) {
+            const int t = amp_src(blk[kZZ[k]]);
+            const int lead = lead_bits(t);
+            const uint32_t size = mag_bits(lead);
+            const uint32_t at = or3_fast(r5, size, eob_of(k));
+            r5 = and3_fast(r5 + 32u, (uint32_t)lead, run_mask);
+            return AcSym{htab[at], amp_bits(t, size), hlen[at]};
+        };
+        // Group sizes by position, from the longest joined strings per wave of photographic content at the
+        // all-ones tables (1 byte per pixel): pairs always fit, fours from position 5 on (3 % of the waves fail
+        // at 5..8, none later), eights from 25 on (13 % fail at 25..32, 1 % at 33..40).
+        auto group = [&](auto first, auto count) {
+            constexpr int K0 = decltype(first)::value, N = decltype(count)::value;
+            AcSym s[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i) s[i] = sym_at(K0 + i);
+            emit_group<GUARD, N>(bw, s, priv);
+        };
+        using std::integral_constant;
+#define JPEGENC_GROUP(K0, N) group(integral_constant<int, K0>{}, integral_constant<int, N>{})
+        JPEGENC_GROUP(1, 2);
+        JPEGENC_GROUP(3, 2);
+        JPEGENC_GROUP(5, 4);
+        JPEGENC_GROUP(9, 4);
+        JPEGENC_GROUP(13, 4);
+        JPEGENC_GROUP(17, 4);
+        JPEGENC_GROUP(21, 4);
+        JPEGENC_GROUP(25, 8);
+        JPEGENC_GROUP(33, 8);
+        JPEGENC_GROUP(41, 8);
+        JPEGENC_GROUP(49, 8);
+        JPEGENC_GROUP(57, 4);
+        JPEGENC_GROUP(61, 2);
+#undef JPEGENC_GROUP
+    } else {
 #pragma unroll
     for (int k = 1; k <= 62; ++k) {
         const int v = blk[kZZ[k]];
@@ -366,6 +470,7 @@ __device__ __forceinline__ void encode_block(const int (&blk)[64], int dc_pred, 
         // zero coefficient (lead == -1, all ones): run + 1 modulo 16; otherwise the run restarts (lead is
         // at most 31 then and has no bit in common with the run field)
         r5 = and3_fast(r5 + 32u, (uint32_t)lead, run_mask);
+    }
     }
     {
         const int v = blk[63];
@@ -1115,7 +1220,7 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
             const int before = __builtin_amdgcn_ds_bpermute((lane - 3) << 2, x[0]);
             const int pred = lane < 3 ? h : before;
             if (!fit)
-                encode_block<false, QUANT>(x, pred, lcomp == 1 && cb_quirk, htab, hlen, flat, bw);
+                encode_block<false, QUANT, !QUANT>(x, pred, lcomp == 1 && cb_quirk, htab, hlen, flat, bw);
             else
                 encode_block<true, QUANT>(x, pred, lcomp == 1 && cb_quirk, htab, hlen, flat, bw);
         }
@@ -1171,7 +1276,7 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
             // DC of the lane before; lane 0 has no source and keeps h (wave_shr:1)
             const int pred = __builtin_amdgcn_update_dpp(h, x[0], 0x138, 0xF, 0xF, false);
             if (!fit)
-                encode_block<false, QUANT>(x, pred, comp == 1 && cb_quirk, htab, hlen, flat, bw);
+                encode_block<false, QUANT, !QUANT>(x, pred, comp == 1 && cb_quirk, htab, hlen, flat, bw);
             else
                 encode_block<true, QUANT>(x, pred, comp == 1 && cb_quirk, htab, hlen, flat, bw);
         }
