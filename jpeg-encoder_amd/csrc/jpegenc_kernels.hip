@@ -1086,6 +1086,10 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
             wave_sync();
     };
     const bool cb_quirk = (p.flags & 2u) != 0;
+    // Symbols are joined before they are appended (emit_group) except where that loses: with quantisation tables the
+    // coder skips whole positions instead, and the large regions are chosen for content whose codes are long
+    // (uniform noise: three pairs in ten exceed 32 bits in some lane, and the encode kernel is 10 % slower with joining).
+    constexpr bool kJoin = !QUANT && REGION != kRegionLarge;
 
     {
         constexpr int kThreads = 64 * WAVES;
@@ -1220,7 +1224,7 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
             const int before = __builtin_amdgcn_ds_bpermute((lane - 3) << 2, x[0]);
             const int pred = lane < 3 ? h : before;
             if (!fit)
-                encode_block<false, QUANT, !QUANT>(x, pred, lcomp == 1 && cb_quirk, htab, hlen, flat, bw);
+                encode_block<false, QUANT, kJoin>(x, pred, lcomp == 1 && cb_quirk, htab, hlen, flat, bw);
             else
                 encode_block<true, QUANT>(x, pred, lcomp == 1 && cb_quirk, htab, hlen, flat, bw);
         }
@@ -1276,7 +1280,7 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
             // DC of the lane before; lane 0 has no source and keeps h (wave_shr:1)
             const int pred = __builtin_amdgcn_update_dpp(h, x[0], 0x138, 0xF, 0xF, false);
             if (!fit)
-                encode_block<false, QUANT, !QUANT>(x, pred, comp == 1 && cb_quirk, htab, hlen, flat, bw);
+                encode_block<false, QUANT, kJoin>(x, pred, comp == 1 && cb_quirk, htab, hlen, flat, bw);
             else
                 encode_block<true, QUANT>(x, pred, comp == 1 && cb_quirk, htab, hlen, flat, bw);
         }
