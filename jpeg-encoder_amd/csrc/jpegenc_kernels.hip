@@ -172,20 +172,23 @@ __device__ __forceinline__ int dot2v(int a, int c, int acc) {
 }
 __host__ __device__ constexpr int cpair(int lo, int hi) { return (int)(((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16)); }
 
-// Inputs as pairs p01 = (x0,x1), p23 = (x2,x3), p76 = (x7,x6), p54 = (x5,x4); a[k] = sum + bias.
+// Inputs as pairs p01 = (x0,x1), p23 = (x2,x3), p76 = (x7,x6), p54 = (x5,x4); a[k] = S * sum + bias.  S = 4 (T
+// times four still fits 16 bits: 4 * 8035 = 32140) moves a rounding position from bit 14 to bit 16, where the
+// rounded value is the upper half of the register.
+template <int S = 1>
 __device__ __forceinline__ void dct8p_acc(int p01, int p23, int p76, int p54, int bias0, int bias, int (&a)[8]) {
     const int s01 = pk_add(p01, p76), s23 = pk_add(p23, p54);  // (s0,s1), (s2,s3)
     const int d01 = pk_sub(p01, p76), d23 = pk_sub(p23, p54);  // (d0,d1), (d2,d3)
     const int e = pk_add_x(s01, s23);                           // (s0+s3, s1+s2)
     const int f = pk_sub_x(s01, s23);                           // (s0-s3, s1-s2)
-    a[0] = dot2(e, cpair(5793, 5793), bias0);
-    a[4] = dot2(e, cpair(5793, -5793), bias);
-    a[2] = dot2(f, cpair(7568, 3135), bias);
-    a[6] = dot2(f, cpair(3135, -7568), bias);
-    a[1] = dot2(d23, cpair(4551, 1598), dot2(d01, cpair(8035, 6811), bias));
-    a[3] = dot2(d23, cpair(-8035, -4551), dot2(d01, cpair(6811, -1598), bias));
-    a[5] = dot2(d23, cpair(1598, 6811), dot2(d01, cpair(4551, -8035), bias));
-    a[7] = dot2(d23, cpair(6811, -8035), dot2(d01, cpair(1598, -4551), bias));
+    a[0] = dot2(e, cpair(S * 5793, S * 5793), bias0);
+    a[4] = dot2(e, cpair(S * 5793, S * -5793), bias);
+    a[2] = dot2(f, cpair(S * 7568, S * 3135), bias);
+    a[6] = dot2(f, cpair(S * 3135, S * -7568), bias);
+    a[1] = dot2(d23, cpair(S * 4551, S * 1598), dot2(d01, cpair(S * 8035, S * 6811), bias));
+    a[3] = dot2(d23, cpair(S * -8035, S * -4551), dot2(d01, cpair(S * 6811, S * -1598), bias));
+    a[5] = dot2(d23, cpair(S * 1598, S * 6811), dot2(d01, cpair(S * 4551, S * -8035), bias));
+    a[7] = dot2(d23, cpair(S * 6811, S * -8035), dot2(d01, cpair(S * 1598, S * -4551), bias));
 }
 // y[k] = (sum + bias) >> sh
 __device__ __forceinline__ void dct8p(int p01, int p23, int p76, int p54, int bias0, int bias, int sh, int (&y)[8]) {
@@ -247,6 +250,25 @@ __device__ __forceinline__ void dct_cols_packed(const int (&pc)[4][8], int (&x)[
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[j * 8 + k] = y[j];
     }
+}
+
+// Pass 2 for the coder that reads pairs: the 64 sums are left with their rounding position at bit 16 (luma's own;
+// chroma's bit 14 by transforming with 4 T), so every coefficient is the upper half of its register and needs no
+// shift, and one v_perm_b32 puts the coefficients of zig-zag positions 2m and 2m+1 into the halves of zp[m]
+// ((Z + 2^13) >> 14 == (4 Z + 2^15) >> 16; |4 Z| < 2^27).
+template <bool LUMA>
+__device__ __forceinline__ void dct_cols_pairs(const int (&pc)[4][8], int (&zp)[32]) {
+    int acc[64];  // [j*8+k], j = vertical frequency
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        int y[8];
+        dct8p_acc<LUMA ? 1 : 4>(pc[0][k], pc[1][k], pc[3][k], pc[2][k], 1 << 15, 1 << 15, y);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j * 8 + k] = y[j];
+    }
+#pragma unroll
+    for (int m = 0; m < 32; ++m)
+        zp[m] = (int)__builtin_amdgcn_perm((uint32_t)acc[kZZ[2 * m + 1]], (uint32_t)acc[kZZ[2 * m]], 0x07060302u);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -481,6 +503,140 @@ __device__ __forceinline__ void encode_block(const int (&blk)[64], int dc_pred, 
         const uint32_t zmask = (uint32_t)(lead >> 31);
         const uint32_t at = ((r5 | size) & ~zmask) | ((uint32_t)kHtabEob & zmask);
         bw_emit<GUARD>(bw, htab[at], amp_bits(t, size), hlen[at], priv);
+    }
+}
+
+// ---- the coder on pairs of coefficients ------------------------------------------------------------------
+// zp[m] = (z[2m], z[2m+1]) as 16-bit halves (dct_cols_pairs).  The amplitude source t = v - (v < 0) of both comes
+// from two packed instructions, the leading-bit count reads its half through an SDWA operand select, and the
+// amplitude's bit field starts at bit 0 or 16: nothing is unpacked.  The group-of-eight tests OR whole
+// registers (a pair never straddles a group).  Same symbols, same order as encode_block.
+__device__ __forceinline__ int pk_amp_src(int p) {
+    int s, t;
+    asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(s) : "v"(p));  // (both halves shift by the constant's low half)
+    asm("v_pk_add_i16 %0, %1, %2" : "=v"(t) : "v"(p), "v"(s));
+    return t;
+}
+template <int HALF>
+__device__ __forceinline__ int lead_bits_half(int t2) {
+    int lead;
+    if constexpr (HALF == 0)
+        asm("v_ffbh_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(lead) : "v"(t2));
+    else
+        asm("v_ffbh_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(lead) : "v"(t2));
+    return lead;
+}
+
+template <bool GUARD, bool MERGE>
+__device__ __forceinline__ void encode_block_pairs(const int (&zp)[32], int dc, int dc_pred, bool cb_eob_quirk,
+                                                   const uint32_t* htab, const uint8_t* hlen, uint32_t* priv,
+                                                   BitWriter& bw) {
+    {   // DC difference, 12 bit (cr_huff.sv:1317)
+        const int t = amp_src(dc - dc_pred);
+        const uint32_t size = mag_bits(lead_bits(t));
+        const uint32_t at = ((uint32_t)size << 5) | kHtabDcSize;
+        bw_emit<GUARD>(bw, htab[at], amp_bits(t, size), hlen[at], priv);
+    }
+    // group-of-eight all-zero tests over zig-zag indices 16..63 (cr_huff.sv:190-204): group g = zp[4g .. 4g+3]
+    const uint32_t o2 = or3_fast((uint32_t)zp[8] | (uint32_t)zp[9], (uint32_t)zp[10], (uint32_t)zp[11]);
+    const uint32_t o3 = or3_fast((uint32_t)zp[12] | (uint32_t)zp[13], (uint32_t)zp[14], (uint32_t)zp[15]);
+    const uint32_t o4 = or3_fast((uint32_t)zp[16] | (uint32_t)zp[17], (uint32_t)zp[18], (uint32_t)zp[19]);
+    const uint32_t o5 = or3_fast((uint32_t)zp[20] | (uint32_t)zp[21], (uint32_t)zp[22], (uint32_t)zp[23]);
+    const uint32_t o6 = or3_fast((uint32_t)zp[24] | (uint32_t)zp[25], (uint32_t)zp[26], (uint32_t)zp[27]);
+    const uint32_t o7 = or3_fast((uint32_t)zp[28] | (uint32_t)zp[29], (uint32_t)zp[30], (uint32_t)zp[31]);
+    const uint32_t t67 = o6 | o7;
+    const uint32_t t47 = or3_fast(o4, o5, t67);
+    const uint32_t eob_a = (or3_fast(o2, o3, t47) == 0) ? 16u : 0u;  // block_counter < 32 (cr_huff.sv:213-231)
+    const uint32_t eob_b = (t47 == 0) ? 16u : 0u;                    // block_counter < 48
+    const uint32_t eob_c = (cb_eob_quirk || t67 == 0) ? 16u : 0u;    // block_counter <= 64; cb_huff.sv:238-243
+    auto eob_of = [&](int k) { return (k < 16) ? 0u : (k + 2 < 32) ? eob_a : (k + 2 < 48) ? eob_b : eob_c; };
+    uint32_t r5 = 0;  // run << 5
+    uint32_t run_mask = 0x1E0u;
+    asm volatile("" : "+v"(run_mask));  // (a vector register: see encode_block)
+    int t2 = pk_amp_src(zp[0]);  // of the pair in hand
+    // lead, size and amplitude of the coefficient at zig-zag position k (positions are visited in order)
+    auto coef_at = [&](auto kc, int& lead, uint32_t& size, uint32_t& amp) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr ((k & 1) == 0) t2 = pk_amp_src(zp[k >> 1]);
+        lead = lead_bits_half<(k & 1)>(t2);
+        size = mag_bits(lead);
+        amp = __builtin_amdgcn_ubfe((uint32_t)t2, (k & 1) ? 16u : 0u, size);
+    };
+    auto sym_at = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        int lead;
+        uint32_t size, amp;
+        coef_at(kc, lead, size, amp);
+        const uint32_t at = or3_fast(r5, size, eob_of(k));
+        r5 = and3_fast(r5 + 32u, (uint32_t)lead, run_mask);
+        return AcSym{htab[at], amp, hlen[at]};
+    };
+    using std::integral_constant;
+    if constexpr (MERGE) {
+        auto group = [&](auto first, auto count) {
+            constexpr int K0 = decltype(first)::value, N = decltype(count)::value;
+            AcSym s[N];
+            s[0] = sym_at(integral_constant<int, K0>{});
+            s[1] = sym_at(integral_constant<int, K0 + 1>{});
+            if constexpr (N >= 4) {
+                s[2] = sym_at(integral_constant<int, K0 + 2>{});
+                s[3] = sym_at(integral_constant<int, K0 + 3>{});
+            }
+            if constexpr (N >= 8) {
+                s[4] = sym_at(integral_constant<int, K0 + 4>{});
+                s[5] = sym_at(integral_constant<int, K0 + 5>{});
+                s[6] = sym_at(integral_constant<int, K0 + 6>{});
+                s[7] = sym_at(integral_constant<int, K0 + 7>{});
+            }
+            emit_group<GUARD, N>(bw, s, priv);
+        };
+#define JPEGENC_GROUP(K0, N) group(integral_constant<int, K0>{}, integral_constant<int, N>{})
+        JPEGENC_GROUP(1, 2);  // (the same groups as in encode_block)
+        JPEGENC_GROUP(3, 2);
+        JPEGENC_GROUP(5, 4);
+        JPEGENC_GROUP(9, 4);
+        JPEGENC_GROUP(13, 4);
+        JPEGENC_GROUP(17, 4);
+        JPEGENC_GROUP(21, 4);
+        JPEGENC_GROUP(25, 8);
+        JPEGENC_GROUP(33, 8);
+        JPEGENC_GROUP(41, 8);
+        JPEGENC_GROUP(49, 8);
+        JPEGENC_GROUP(57, 4);
+        JPEGENC_GROUP(61, 2);
+#undef JPEGENC_GROUP
+    } else {
+        auto single = [&](auto kc) {
+            const AcSym s = sym_at(kc);
+            bw_emit<GUARD>(bw, s.h, s.a, s.l, priv);
+        };
+        auto eight = [&](auto first) {
+            constexpr int K0 = decltype(first)::value;
+            single(integral_constant<int, K0>{});
+            single(integral_constant<int, K0 + 1>{});
+            single(integral_constant<int, K0 + 2>{});
+            single(integral_constant<int, K0 + 3>{});
+            single(integral_constant<int, K0 + 4>{});
+            single(integral_constant<int, K0 + 5>{});
+            if constexpr (K0 + 6 <= 62) single(integral_constant<int, K0 + 6>{});
+            if constexpr (K0 + 7 <= 62) single(integral_constant<int, K0 + 7>{});
+        };
+        eight(integral_constant<int, 1>{});
+        eight(integral_constant<int, 9>{});
+        eight(integral_constant<int, 17>{});
+        eight(integral_constant<int, 25>{});
+        eight(integral_constant<int, 33>{});
+        eight(integral_constant<int, 41>{});
+        eight(integral_constant<int, 49>{});
+        eight(integral_constant<int, 57>{});
+    }
+    {   // the last slot always emits: EOB for a zero, else the ordinary symbol (cr_huff.sv:518, :656)
+        int lead;
+        uint32_t size, amp;
+        coef_at(integral_constant<int, 63>{}, lead, size, amp);
+        const uint32_t zmask = (uint32_t)(lead >> 31);
+        const uint32_t at = ((r5 | size) & ~zmask) | ((uint32_t)kHtabEob & zmask);
+        bw_emit<GUARD>(bw, htab[at], amp, hlen[at], priv);
     }
 }
 
@@ -1090,6 +1246,9 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
     // coder skips whole positions instead, and the large regions are chosen for content whose codes are long
     // (uniform noise: three pairs in ten exceed 32 bits in some lane, and the encode kernel is 10 % slower with joining).
     constexpr bool kJoin = !QUANT && REGION != kRegionLarge;
+    // The coder reads the coefficients as 16-bit pairs (dct_cols_pairs, encode_block_pairs) where there is no
+    // quantiser between transform and coder and a lane codes all three components.
+    constexpr bool kPairs = !QUANT && LPM == 1;
 
     {
         constexpr int kThreads = 64 * WAVES;
@@ -1231,7 +1390,8 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
 #pragma unroll 1
         for (int comp = 0; LPM == 1 && comp < 3; ++comp) {
             const CompCoef cc = comp_coef(comp);
-            int x[64];
+            int x[kPairs ? 1 : 64];
+            [[maybe_unused]] int zp[kPairs ? 32 : 1];
             // The MCU's 192 bytes are fetched again for every component (mostly from L2): holding them in 48
             // registers across the components spills at the register budget of three waves per SIMD,
             // and the scratch traffic then exceeds the saved fetches; with large regions and two waves per SIMD
@@ -1257,7 +1417,10 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
                     colour_row<0>(raw, 2 * i + 1, cc, p1);
                     dct_row_pair<true>(p0, p1, i >= 2, pc[i]);
                 }
-                dct_cols_packed<true>(pc, x);
+                if constexpr (kPairs)
+                    dct_cols_pairs<true>(pc, zp);
+                else
+                    dct_cols_packed<true>(pc, x);
                 asm volatile("; luma dct done" ::: "memory");
             } else {
                 int pc[4][8];
@@ -1268,7 +1431,10 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
                     colour_row<WRAP ? 1 : 2>(raw, 2 * i + 1, cc, p1);
                     dct_row_pair<false>(p0, p1, i >= 2, pc[i]);
                 }
-                dct_cols_packed<false>(pc, x);
+                if constexpr (kPairs)
+                    dct_cols_pairs<false>(pc, zp);
+                else
+                    dct_cols_packed<false>(pc, x);
                 asm volatile("; chroma dct done" ::: "memory");
             }
             if constexpr (QUANT) {
@@ -1277,12 +1443,20 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
                 for (int i = 0; i < 64; ++i) x[i] = quant(x[i], qm[i]);
             }
             const int h = (comp == 0) ? halo[0] : (comp == 1) ? halo[1] : halo[2];
+            const int dc = kPairs ? (zp[0] << 16) >> 16 : x[0];
             // DC of the lane before; lane 0 has no source and keeps h (wave_shr:1)
-            const int pred = __builtin_amdgcn_update_dpp(h, x[0], 0x138, 0xF, 0xF, false);
-            if (!fit)
-                encode_block<false, QUANT, kJoin>(x, pred, comp == 1 && cb_quirk, htab, hlen, flat, bw);
-            else
-                encode_block<true, QUANT>(x, pred, comp == 1 && cb_quirk, htab, hlen, flat, bw);
+            const int pred = __builtin_amdgcn_update_dpp(h, dc, 0x138, 0xF, 0xF, false);
+            if constexpr (kPairs) {
+                if (!fit)
+                    encode_block_pairs<false, kJoin>(zp, dc, pred, comp == 1 && cb_quirk, htab, hlen, flat, bw);
+                else
+                    encode_block_pairs<true, false>(zp, dc, pred, comp == 1 && cb_quirk, htab, hlen, flat, bw);
+            } else {
+                if (!fit)
+                    encode_block<false, QUANT, kJoin>(x, pred, comp == 1 && cb_quirk, htab, hlen, flat, bw);
+                else
+                    encode_block<true, QUANT>(x, pred, comp == 1 && cb_quirk, htab, hlen, flat, bw);
+            }
         }
         const uint32_t Lall = valid ? (bw.T - base * 32u) : 0u;
         const uint32_t cap = fit ? need_lds[lane] - 2u : (uint32_t)kRegionWords - 2u;
