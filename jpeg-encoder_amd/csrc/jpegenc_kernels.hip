@@ -20,6 +20,7 @@
 //               1053-1304 (zig-zag), 1317-1486 (sizes), 1553-2082 (tables); y_huff.sv:184-193; cb_huff.sv:230-243
 //   interleave  rtl/5_fifo/fifo_out.sv:195-197, 222-243, 257-266
 //   stuffing    rtl/5_fifo/ff_checker.sv:96-179, 265-360
+#include <initializer_list>
 #include <type_traits>
 
 #include "jpegenc_internal.h"
@@ -252,23 +253,51 @@ __device__ __forceinline__ void dct_cols_packed(const int (&pc)[4][8], int (&x)[
     }
 }
 
-// Pass 2 for the coder that reads pairs: the 64 sums are left with their rounding position at bit 16 (luma's own;
-// chroma's bit 14 by transforming with 4 T), so every coefficient is the upper half of its register and needs no
-// shift, and one v_perm_b32 puts the coefficients of zig-zag positions 2m and 2m+1 into the halves of zp[m]
-// ((Z + 2^13) >> 14 == (4 Z + 2^15) >> 16; |4 Z| < 2^27).
+// Pass 2 for the coder that reads pairs.  The sums are left with their rounding position at bit 16 (luma's own;
+// chroma's bit 14 by transforming with 4 T: (Z + 2^13) >> 14 == (4 Z + 2^15) >> 16, |4 Z| < 2^27), so every
+// coefficient is the upper half of its register and needs no shift.  One v_perm_b32 puts the coefficients of two
+// vertical frequencies of a column into the halves of a register, and two packed instructions turn both into
+// the coder's amplitude source t = v - (v < 0) (zero exactly when v is): tp[4 k + i] = (t of frequency (2 i, k),
+// t of (2 i + 1, k)).  Pairs within a column keep only the column's eight sums alive.  dc = the DC coefficient.
+__device__ __forceinline__ int pk_amp_src(int p) {
+    int s, t;
+    asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(s) : "v"(p));  // (both halves shift by the constant's low half)
+    asm("v_pk_add_i16 %0, %1, %2" : "=v"(t) : "v"(p), "v"(s));
+    return t;
+}
 template <bool LUMA>
-__device__ __forceinline__ void dct_cols_pairs(const int (&pc)[4][8], int (&zp)[32]) {
-    int acc[64];  // [j*8+k], j = vertical frequency
+__device__ __forceinline__ void dct_cols_pairs(const int (&pc)[4][8], int (&tp)[32], int& dc) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         int y[8];
         dct8p_acc<LUMA ? 1 : 4>(pc[0][k], pc[1][k], pc[3][k], pc[2][k], 1 << 15, 1 << 15, y);
+        if (k == 0) dc = y[0] >> 16;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j * 8 + k] = y[j];
+        for (int i = 0; i < 4; ++i)
+            tp[4 * k + i] = pk_amp_src((int)__builtin_amdgcn_perm((uint32_t)y[2 * i + 1], (uint32_t)y[2 * i], 0x07060302u));
     }
-#pragma unroll
-    for (int m = 0; m < 32; ++m)
-        zp[m] = (int)__builtin_amdgcn_perm((uint32_t)acc[kZZ[2 * m + 1]], (uint32_t)acc[kZZ[2 * m]], 0x07060302u);
+}
+// where the coefficient of zig-zag position z sits in tp
+__host__ __device__ constexpr int pair_reg(int z) { return (kZZ[z] & 7) * 4 + (kZZ[z] >> 4); }
+__host__ __device__ constexpr int pair_half(int z) { return (kZZ[z] >> 3) & 1; }
+// The ranges of zig-zag positions that the end-of-block tests tell apart: below 16, 16..31, 32..47, 48..63.  True
+// if exactly the listed registers of tp hold a position of range `lower` in the lower half and one of range
+// `upper` in the upper half.
+__host__ __device__ constexpr int zz_range(int z) { return z < 16 ? 0 : z < 32 ? 1 : z < 48 ? 2 : 3; }
+__host__ __device__ constexpr bool pairs_of_kind(int lower, int upper, std::initializer_list<int> regs) {
+    int found = 0;
+    for (int z = 0; z < 64; z += 1) {
+        if (pair_half(z) != 0 || zz_range(z) != lower) continue;
+        int up = -1;  // the position in the upper half of the same register
+        for (int y = 0; y < 64; ++y)
+            if (pair_reg(y) == pair_reg(z) && pair_half(y) == 1) up = y;
+        if (zz_range(up) != upper) continue;
+        bool listed = false;
+        for (int r : regs) listed = listed || r == pair_reg(z);
+        if (!listed) return false;
+        ++found;
+    }
+    return found == (int)regs.size();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -507,16 +536,9 @@ __device__ __forceinline__ void encode_block(const int (&blk)[64], int dc_pred, 
 }
 
 // ---- the coder on pairs of coefficients ------------------------------------------------------------------
-// zp[m] = (z[2m], z[2m+1]) as 16-bit halves (dct_cols_pairs).  The amplitude source t = v - (v < 0) of both comes
-// from two packed instructions, the leading-bit count reads its half through an SDWA operand select, and the
-// amplitude's bit field starts at bit 0 or 16: nothing is unpacked.  The group-of-eight tests OR whole
-// registers (a pair never straddles a group).  Same symbols, same order as encode_block.
-__device__ __forceinline__ int pk_amp_src(int p) {
-    int s, t;
-    asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(s) : "v"(p));  // (both halves shift by the constant's low half)
-    asm("v_pk_add_i16 %0, %1, %2" : "=v"(t) : "v"(p), "v"(s));
-    return t;
-}
+// tp = the amplitude sources as 16-bit halves (dct_cols_pairs).  The leading-bit count reads its half through an
+// SDWA operand select and the amplitude's bit field starts at bit 0 or 16: nothing is unpacked.  Same symbols, same
+// order as encode_block.
 template <int HALF>
 __device__ __forceinline__ int lead_bits_half(int t2) {
     int lead;
@@ -528,7 +550,7 @@ __device__ __forceinline__ int lead_bits_half(int t2) {
 }
 
 template <bool GUARD, bool MERGE>
-__device__ __forceinline__ void encode_block_pairs(const int (&zp)[32], int dc, int dc_pred, bool cb_eob_quirk,
+__device__ __forceinline__ void encode_block_pairs(const int (&tp)[32], int dc, int dc_pred, bool cb_eob_quirk,
                                                    const uint32_t* htab, const uint8_t* hlen, uint32_t* priv,
                                                    BitWriter& bw) {
     {   // DC difference, 12 bit (cr_huff.sv:1317)
@@ -537,30 +559,37 @@ __device__ __forceinline__ void encode_block_pairs(const int (&zp)[32], int dc, 
         const uint32_t at = ((uint32_t)size << 5) | kHtabDcSize;
         bw_emit<GUARD>(bw, htab[at], amp_bits(t, size), hlen[at], priv);
     }
-    // group-of-eight all-zero tests over zig-zag indices 16..63 (cr_huff.sv:190-204): group g = zp[4g .. 4g+3]
-    const uint32_t o2 = or3_fast((uint32_t)zp[8] | (uint32_t)zp[9], (uint32_t)zp[10], (uint32_t)zp[11]);
-    const uint32_t o3 = or3_fast((uint32_t)zp[12] | (uint32_t)zp[13], (uint32_t)zp[14], (uint32_t)zp[15]);
-    const uint32_t o4 = or3_fast((uint32_t)zp[16] | (uint32_t)zp[17], (uint32_t)zp[18], (uint32_t)zp[19]);
-    const uint32_t o5 = or3_fast((uint32_t)zp[20] | (uint32_t)zp[21], (uint32_t)zp[22], (uint32_t)zp[23]);
-    const uint32_t o6 = or3_fast((uint32_t)zp[24] | (uint32_t)zp[25], (uint32_t)zp[26], (uint32_t)zp[27]);
-    const uint32_t o7 = or3_fast((uint32_t)zp[28] | (uint32_t)zp[29], (uint32_t)zp[30], (uint32_t)zp[31]);
-    const uint32_t t67 = o6 | o7;
-    const uint32_t t47 = or3_fast(o4, o5, t67);
-    const uint32_t eob_a = (or3_fast(o2, o3, t47) == 0) ? 16u : 0u;  // block_counter < 32 (cr_huff.sv:213-231)
+    // The group-of-eight all-zero tests (cr_huff.sv:190-204) only ever ask about zig-zag positions 16..31, 32..47
+    // and 48..63 together with everything behind them.  Of the registers of tp, some hold two positions of one of
+    // these ranges, some a position of one range in the lower half and of the next in the upper half, some a
+    // position below 16 in the lower half: ORed by kind, then the halves that count are picked.
+    const uint32_t ga_both = or3_fast((uint32_t)tp[6], (uint32_t)tp[13], (uint32_t)tp[17]) | (uint32_t)tp[24];
+    const uint32_t ga_hi = or3_fast((uint32_t)tp[2], (uint32_t)tp[9], (uint32_t)tp[16]) | (uint32_t)tp[20];
+    const uint32_t gab = or3_fast((uint32_t)tp[3], (uint32_t)tp[10], (uint32_t)tp[21]) | (uint32_t)tp[28];   // lower: 16..31, upper: 32..47
+    const uint32_t gb_both = or3_fast((uint32_t)tp[7], (uint32_t)tp[14], (uint32_t)tp[18]) | (uint32_t)tp[25];
+    const uint32_t gbc = or3_fast((uint32_t)tp[11], (uint32_t)tp[15], (uint32_t)tp[22]) | (uint32_t)tp[29];  // lower: 32..47, upper: 48..63
+    const uint32_t gc_both = or3_fast(or3_fast((uint32_t)tp[19], (uint32_t)tp[23], (uint32_t)tp[26]), (uint32_t)tp[27], (uint32_t)tp[30]) | (uint32_t)tp[31];
+    static_assert(pairs_of_kind(1, 1, {6, 13, 17, 24}) && pairs_of_kind(0, 1, {2, 9, 16, 20}) && pairs_of_kind(1, 2, {3, 10, 21, 28}) &&
+                      pairs_of_kind(2, 2, {7, 14, 18, 25}) && pairs_of_kind(2, 3, {11, 15, 22, 29}) &&
+                      pairs_of_kind(3, 3, {19, 23, 26, 27, 30, 31}) && pairs_of_kind(0, 0, {0, 1, 4, 5, 8, 12}),
+                  "every register of tp is in the list of its kind");
+    const uint32_t t67 = gc_both | (gbc & 0xFFFF0000u);                                  // positions 48..63
+    const uint32_t t47 = or3_fast(t67, gb_both, (gbc & 0xFFFFu) | (gab & 0xFFFF0000u));  // 32..63
+    const uint32_t t27 = or3_fast(t47, ga_both, (gab & 0xFFFFu) | (ga_hi & 0xFFFF0000u));  // 16..63
+    const uint32_t eob_a = (t27 == 0) ? 16u : 0u;                    // block_counter < 32 (cr_huff.sv:213-231)
     const uint32_t eob_b = (t47 == 0) ? 16u : 0u;                    // block_counter < 48
     const uint32_t eob_c = (cb_eob_quirk || t67 == 0) ? 16u : 0u;    // block_counter <= 64; cb_huff.sv:238-243
     auto eob_of = [&](int k) { return (k < 16) ? 0u : (k + 2 < 32) ? eob_a : (k + 2 < 48) ? eob_b : eob_c; };
     uint32_t r5 = 0;  // run << 5
     uint32_t run_mask = 0x1E0u;
     asm volatile("" : "+v"(run_mask));  // (a vector register: see encode_block)
-    int t2 = pk_amp_src(zp[0]);  // of the pair in hand
-    // lead, size and amplitude of the coefficient at zig-zag position k (positions are visited in order)
+    // lead, size and amplitude of the coefficient at zig-zag position k
     auto coef_at = [&](auto kc, int& lead, uint32_t& size, uint32_t& amp) {
         constexpr int k = decltype(kc)::value;
-        if constexpr ((k & 1) == 0) t2 = pk_amp_src(zp[k >> 1]);
-        lead = lead_bits_half<(k & 1)>(t2);
+        const int t2 = tp[pair_reg(k)];
+        lead = lead_bits_half<pair_half(k)>(t2);
         size = mag_bits(lead);
-        amp = __builtin_amdgcn_ubfe((uint32_t)t2, (k & 1) ? 16u : 0u, size);
+        amp = __builtin_amdgcn_ubfe((uint32_t)t2, pair_half(k) ? 16u : 0u, size);
     };
     auto sym_at = [&](auto kc) {
         constexpr int k = decltype(kc)::value;
@@ -1391,7 +1420,7 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
         for (int comp = 0; LPM == 1 && comp < 3; ++comp) {
             const CompCoef cc = comp_coef(comp);
             int x[kPairs ? 1 : 64];
-            [[maybe_unused]] int zp[kPairs ? 32 : 1];
+            [[maybe_unused]] int tp[kPairs ? 32 : 1], dc_pair = 0;
             // The MCU's 192 bytes are fetched again for every component (mostly from L2): holding them in 48
             // registers across the components spills at the register budget of three waves per SIMD,
             // and the scratch traffic then exceeds the saved fetches; with large regions and two waves per SIMD
@@ -1418,7 +1447,7 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
                     dct_row_pair<true>(p0, p1, i >= 2, pc[i]);
                 }
                 if constexpr (kPairs)
-                    dct_cols_pairs<true>(pc, zp);
+                    dct_cols_pairs<true>(pc, tp, dc_pair);
                 else
                     dct_cols_packed<true>(pc, x);
                 asm volatile("; luma dct done" ::: "memory");
@@ -1432,7 +1461,7 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
                     dct_row_pair<false>(p0, p1, i >= 2, pc[i]);
                 }
                 if constexpr (kPairs)
-                    dct_cols_pairs<false>(pc, zp);
+                    dct_cols_pairs<false>(pc, tp, dc_pair);
                 else
                     dct_cols_packed<false>(pc, x);
                 asm volatile("; chroma dct done" ::: "memory");
@@ -1443,14 +1472,14 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
                 for (int i = 0; i < 64; ++i) x[i] = quant(x[i], qm[i]);
             }
             const int h = (comp == 0) ? halo[0] : (comp == 1) ? halo[1] : halo[2];
-            const int dc = kPairs ? (zp[0] << 16) >> 16 : x[0];
+            const int dc = kPairs ? dc_pair : x[0];
             // DC of the lane before; lane 0 has no source and keeps h (wave_shr:1)
             const int pred = __builtin_amdgcn_update_dpp(h, dc, 0x138, 0xF, 0xF, false);
             if constexpr (kPairs) {
                 if (!fit)
-                    encode_block_pairs<false, kJoin>(zp, dc, pred, comp == 1 && cb_quirk, htab, hlen, flat, bw);
+                    encode_block_pairs<false, kJoin>(tp, dc, pred, comp == 1 && cb_quirk, htab, hlen, flat, bw);
                 else
-                    encode_block_pairs<true, false>(zp, dc, pred, comp == 1 && cb_quirk, htab, hlen, flat, bw);
+                    encode_block_pairs<true, false>(tp, dc, pred, comp == 1 && cb_quirk, htab, hlen, flat, bw);
             } else {
                 if (!fit)
                     encode_block<false, QUANT, kJoin>(x, pred, comp == 1 && cb_quirk, htab, hlen, flat, bw);
