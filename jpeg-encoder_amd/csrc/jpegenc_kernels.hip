@@ -215,11 +215,23 @@ __device__ __forceinline__ int shift_pack(int lo, int hi, int sh) {
 template <bool LUMA>
 __device__ __forceinline__ void dct_row_pair(const int (&p0)[4], const int (&p1)[4], bool lower_half, int (&col)[8]) {
     int a0[8], a1[8];
-    dct8p_acc(p0[0], p0[1], p0[2], p0[3], DctK<LUMA>::b1 - JPEGENC_DCT_LEVEL_SHIFT, DctK<LUMA>::b1, a0);
-    dct8p_acc(p1[0], p1[1], p1[2], p1[3], DctK<LUMA>::b1 - JPEGENC_DCT_LEVEL_SHIFT, DctK<LUMA>::b1, a1);
+    if constexpr (LUMA) {
+        dct8p_acc(p0[0], p0[1], p0[2], p0[3], DctK<LUMA>::b1 - JPEGENC_DCT_LEVEL_SHIFT, DctK<LUMA>::b1, a0);
+        dct8p_acc(p1[0], p1[1], p1[2], p1[3], DctK<LUMA>::b1 - JPEGENC_DCT_LEVEL_SHIFT, DctK<LUMA>::b1, a1);
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-        col[k] = lower_half ? shift_pack(a1[k], a0[k], DctK<LUMA>::sh1) : shift_pack(a0[k], a1[k], DctK<LUMA>::sh1);
+        for (int k = 0; k < 8; ++k)
+            col[k] = lower_half ? shift_pack(a1[k], a0[k], DctK<LUMA>::sh1) : shift_pack(a0[k], a1[k], DctK<LUMA>::sh1);
+    } else {
+        // Chroma rounds at bit 14: with 4 T (and four times the level shift) the rounded value is the upper half of
+        // the sum, (A + 2^13) >> 14 == (4 A + 2^15) >> 16 with |4 A| < 2^27, and one v_perm_b32 packs two of them
+        // where two shifts did.
+        dct8p_acc<4>(p0[0], p0[1], p0[2], p0[3], (1 << 15) - 4 * JPEGENC_DCT_LEVEL_SHIFT, 1 << 15, a0);
+        dct8p_acc<4>(p1[0], p1[1], p1[2], p1[3], (1 << 15) - 4 * JPEGENC_DCT_LEVEL_SHIFT, 1 << 15, a1);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            col[k] = lower_half ? (int)__builtin_amdgcn_perm((uint32_t)a0[k], (uint32_t)a1[k], 0x07060302u)
+                                : (int)__builtin_amdgcn_perm((uint32_t)a1[k], (uint32_t)a0[k], 0x07060302u);
+    }
 }
 
 // The two passes with the rounding positions as values (one component per lane: luma and chroma lanes side by side).
