@@ -38,7 +38,7 @@ def parse_args():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--content", choices=["natural", "noise"], default="natural")
-    ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the batch timed on the CPU oracle")
+    ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the batch timed on the CPU oracle")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--persistence", type=float, default=None,
                     help="octave amplitude ratio of the natural-like generator (default 0.7; larger = more detail)")
