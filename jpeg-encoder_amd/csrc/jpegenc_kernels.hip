@@ -2055,7 +2055,7 @@ hipError_t static_workspace(void** ptr) {
 // ------------------------------------------------------------------------------------------------
 // This file is compiled twice.  The variants of k_encode_chunks with a quantiser are built in a translation
 // unit of their own (-DJPEGENC_TU_QUANT) with the scheduler's max-ILP strategy: there it removes their spills
-// (9 % faster), while the variants for the all-ones tables lose 5 % under it and keep the default strategy.
+// (9 % faster); of the variants for the all-ones tables only the common one with small regions joins them there.
 // (Every launcher first takes any error an earlier, unrelated HIP call has left pending: what it returns is
 // then the outcome of its own launch.)
 template <int ALIGN, bool QUANT, int REGION, bool FUSED = false, int WAVES = 1, int LPM = 1>
@@ -2075,8 +2075,15 @@ hipError_t launch_encode_quant(const EncodeParams& p, dim3 grid, int align, hipS
     if (align >= 4) return launch_encode_b<4, true, kRegionBasic>(p, grid, s);
     return launch_encode_b<1, true, kRegionBasic>(p, grid, s);
 }
+// The common variant with small regions is built here as well: since its coder joins symbols and reads coefficient
+// pairs it has registers to spare, and the max-ILP strategy makes it 1.6 % faster (the large-region variant loses
+// 15 % under it on uniform noise, the single-launch variants gain nothing: they stay with the default strategy).
+hipError_t launch_encode_small(const EncodeParams& p, dim3 grid, hipStream_t s) {
+    return launch_encode_b<8, false, kRegionSmall, false, kSmallWaves>(p, grid, s);
+}
 #else
 hipError_t launch_encode_quant(const EncodeParams& p, dim3 grid, int align, hipStream_t s);
+hipError_t launch_encode_small(const EncodeParams& p, dim3 grid, hipStream_t s);
 
 hipError_t launch_encode(const EncodeParams& p_in, uint32_t n_images, int align, hipStream_t s) {
     EncodeParams p = p_in;
@@ -2098,7 +2105,7 @@ hipError_t launch_encode(const EncodeParams& p_in, uint32_t n_images, int align,
     // large regions exist for the common variant only (8-byte-aligned rows, all-ones tables: quantised streams are short)
     if (align >= 8)
         return p.large_regions ? launch_encode_b<8, false, kRegionLarge, false, kLargeWaves>(p, grid, s)
-                               : launch_encode_b<8, false, kRegionSmall, false, kSmallWaves>(p, grid, s);
+                               : launch_encode_small(p, grid, s);
     if (align >= 4) return launch_encode_b<4, false, kRegionBasic>(p, grid, s);
     return launch_encode_b<1, false, kRegionBasic>(p, grid, s);
 }
