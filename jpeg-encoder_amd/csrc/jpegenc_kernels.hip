@@ -957,10 +957,11 @@ __device__ __forceinline__ void write_chunk(const StuffParams& p, const uint32_t
         fill += (sb == 0xFFu) ? 2u : 1u;
     }
 
-    auto flush = [&](bool final_pad) {
+    auto flush = [&](bool final_pad, bool quads_only = false) {
         // stores the complete words of the stage, four per lane and turn; keeps the residual bytes for
-        // the next step
-        const uint32_t nwords = final_pad ? ((fill + 3u) >> 2) : (fill >> 2);
+        // the next step.  quads_only (between the steps of a chunk): only whole groups of four words, so that every
+        // lane takes the 16-byte store and up to 15 bytes stay behind, not 3
+        const uint32_t nwords = final_pad ? ((fill + 3u) >> 2) : quads_only ? ((fill >> 4) << 2) : (fill >> 2);
         for (uint32_t i = 4u * lane; i < nwords; i += 256) {
             const uint4 raw = *reinterpret_cast<const uint4*>(stage + 4 * i);
             const uint64_t gw = wbase + i;
@@ -985,8 +986,8 @@ __device__ __forceinline__ void write_chunk(const StuffParams& p, const uint32_t
         }
         wave_sync();
         if (nwords) {
-            const uint32_t rest = final_pad ? 0u : (fill & 3u);
-            if (lane < rest) stage[lane] = stage[nwords * 4 + lane];  // reads and writes are disjoint words
+            const uint32_t rest = final_pad ? 0u : fill - 4u * nwords;  // at most 3 bytes, 15 with quads_only (nwords >= 4 then)
+            if ((uint32_t)lane < rest) stage[lane] = stage[nwords * 4 + lane];  // reads and writes are disjoint words
             wbase += nwords;
             fill = rest;
             head = 0;
@@ -1046,7 +1047,9 @@ __device__ __forceinline__ void write_chunk(const StuffParams& p, const uint32_t
             const uint32_t incl = wave_incl_scan_dpp(cnt);
             const uint32_t it_ff = readlane_u32(incl, 63);
             uint32_t a = fill + 16u * (uint32_t)lane + (incl - cnt);  // stage offset of this lane's first byte
-            if (nvalid == 16 && cnt == 0) {
+            if (cnt == 0) {
+                // (A lane with fewer than 16 bytes left -- the chunk's last, and the lanes behind it -- stores 16
+                // all the same: what it adds lies behind the chunk's last byte, inside the stage, and is never used.)
                 uint32_t t[4] = {__builtin_bswap32(v[0]), __builtin_bswap32(v[1]), __builtin_bswap32(v[2]),
                                  __builtin_bswap32(v[3])};
                 __builtin_memcpy(&stage[a], t, 16);  // byte-aligned 16-byte store
@@ -1073,12 +1076,13 @@ __device__ __forceinline__ void write_chunk(const StuffParams& p, const uint32_t
             }
             fill += min(1024u, nm - base) + it_ff;
             wave_sync();
-            flush(false);
+            flush(false, true);
         }
     }
 
     const bool last = (c == p.cpi - 1) && p.eof;
     if (!last) {
+        flush(false);  // the whole words still in the stage
         // bytes after the last whole word belong to a word shared with the next chunk
         if ((uint32_t)lane >= head && (uint32_t)lane < fill) {
             const uint64_t ga = wbase * 4 + lane;
