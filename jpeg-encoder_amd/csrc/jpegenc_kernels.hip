@@ -916,9 +916,7 @@ __device__ __forceinline__ uint32_t count_owned_ff(const uint32_t* S, uint4 (&w)
             }
         }
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d);
-    return total;
+    return readlane_u32(wave_incl_scan_dpp(total), 63);  // the wave's sum
 }
 
 // Writes the stuffed bytes of one chunk (stream S of n bits at bit o of the image's stream, ff_before 0xFF bytes
