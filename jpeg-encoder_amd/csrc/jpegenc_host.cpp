@@ -119,6 +119,7 @@ struct jpegenc_ctx {
 
     // Single-launch form of small launches (jpegenc_set_pipeline): hand-off words of the chunks, 3 per chunk
     int pipeline = JPEGENC_PIPELINE_AUTO;
+    int n_cu = 0;  // compute units of the device
     DevBuf<uint64_t> state;
 
     // jpegenc_encode_batch_noalloc: this device's copy of the library's static workspace
@@ -431,7 +432,15 @@ int run_group(jpegenc_ctx* ctx, const Workspace& ws, bool timed, const Plan& pl,
     // once.  Measured on 1080p batches against count + scan + write: 1.41 against 1.44 ms of kernel time per 1024
     // frames, 1.5 to 3 % less per step (no scan launches, 2.3 GB less read); 0.73 against 0.74 ms at 512 frames;
     // with too few workgroups it loses (16-wave workgroups: 8 % slower at 128 frames): used from 512 images on.
-    const bool per_image = n >= kStuffImageMinImages && cpi >= kStuffImageMinChunks;
+    // (from 256 images on when the image's chunk counts fit the LDS of its workgroup: the form without a barrier per
+    // round, with 16 waves per workgroup below 512 images: 256 x 3840x2160 1.25 against 1.44 ms)
+    bool per_image = cpi >= kStuffImageMinChunks && n >= kStuffImageMinImages;
+    if (!per_image && cpi >= 128 && cpi <= kStuffImageLdsChunks && ctx->n_cu > 0 && n >= uint32_t(ctx->n_cu)) {
+        // one 16-wave workgroup per CU: only when the images fill the CUs in whole turns or nearly (384 images on
+        // 256 CUs: 0.63 against 0.55 ms)
+        const uint32_t turns = (n + uint32_t(ctx->n_cu) - 1) / uint32_t(ctx->n_cu);
+        per_image = uint64_t(n) * 10 >= uint64_t(turns) * uint32_t(ctx->n_cu) * 9;
+    }
     // a frame or a few: the stuffing kernels work out the prefixes themselves, two launches fewer
     const bool inline_scan = !per_image && uint64_t(n) * cpi <= kInlineScanChunks && cpi <= kInlineScanMaxCpi;
     ScanParams sp;
@@ -611,6 +620,7 @@ int jpegenc_create(jpegenc_ctx** out, const jpegenc_config* cfg) {
         delete ctx;
         return JPEGENC_E_HIP;  // the code object is gfx950-only
     }
+    if (e == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ws_event, hipEventDisableTiming);
     // the address of the static workspace on this device (every device holds its own copy at its own address)

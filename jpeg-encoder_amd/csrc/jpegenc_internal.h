@@ -123,6 +123,9 @@ hipError_t launch_encode(const EncodeParams& p, uint32_t n_images, int align, hi
 hipError_t launch_scan(const ScanParams& p, uint32_t n_images, hipStream_t s);
 hipError_t launch_stuff_count(const StuffParams& p, uint32_t n_images, hipStream_t s);
 hipError_t launch_stuff_write(const StuffParams& p, uint32_t n_images, hipStream_t s);
+// Images of at most this many chunks take the per-image stuffing kernel without a barrier per round (every chunk's
+// 0xFF count has a word in the LDS of the image's workgroup: 16 KB).
+constexpr uint32_t kStuffImageLdsChunks = 4096;
 // count + write of whole images in one launch (one workgroup per image; for batches of many images)
 hipError_t launch_stuff_image(const StuffParams& p, uint32_t n_images, hipStream_t s);
 

@@ -1848,7 +1848,6 @@ __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_write(StuffParams p,
 // chunks.  Both stuffing steps are bound by vector instructions (87 % of the write step's time), not by
 // memory, which is why reading the streams once buys so little.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t kStuffImageLdsChunks = 4096;  // chunks per image whose 0xFF counts have a word each in the LDS (16 KB)
 constexpr int kImageWaves = 8;  // measured on 1024 x 1080p: 16 waves 1.49 ms, 8 waves 1.41 ms, 4 waves 1.40 ms (and 1.10 against 0.73 ms at 512 frames)
 
 template <int SPEC>
@@ -1897,20 +1896,21 @@ __global__ __launch_bounds__(64 * kImageWaves) void k_stuff_image(StuffParams p)
 // anything, so no wait depends on another wait; the waves drift apart, and one wave's loads and stores overlap
 // another's arithmetic -- with a barrier per round all eight wait for memory together and compute together.
 constexpr uint32_t kFfValid = 0x80000000u;
-template <int SPEC>
-__global__ __launch_bounds__(64 * kImageWaves) void k_stuff_image_flags(StuffParams p) {
-    __shared__ __attribute__((aligned(16))) uint8_t stage_all[kImageWaves][kStageBytes];
+// WAVES per workgroup: 8 for 512 images and more (two workgroups per CU), 16 for 256 to 511 (one per CU).
+template <int SPEC, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_stuff_image_flags(StuffParams p) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage_all[WAVES][kStageBytes];
     __shared__ uint32_t ff_pub[kStuffImageLdsChunks];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint8_t* const stage = stage_all[wave];
     const uint32_t img = blockIdx.x;
     const uint32_t first = img * p.cpi;
-    for (uint32_t i = threadIdx.x; i < p.cpi; i += 64 * kImageWaves) ff_pub[i] = 0u;
+    for (uint32_t i = threadIdx.x; i < p.cpi; i += 64 * WAVES) ff_pub[i] = 0u;
     __syncthreads();
     uint64_t bits_before = p.bit_base;      // of the rounds done so far
     uint64_t ff_upto = 0;                   // 0xFF bytes of the chunks up to and including this wave's previous one
     uint32_t tail8_before = p.pred_tail8;   // last 8 bits before this round
-    for (uint32_t c0 = 0; c0 + wave < p.cpi; c0 += kImageWaves) {
+    for (uint32_t c0 = 0; c0 + wave < p.cpi; c0 += WAVES) {
         const uint32_t c = c0 + wave;
         const uint32_t gid = first + c;
         const uint32_t* S = p.slots + (uint64_t)gid * kSlotWords;
@@ -1918,7 +1918,7 @@ __global__ __launch_bounds__(64 * kImageWaves) void k_stuff_image_flags(StuffPar
         uint32_t w4[kStuffDepth];
         request_chunk<SPEC>(S, lane, w, w4);
         // the round's bit counts: lane j holds chunk c0 + j
-        const uint32_t word = (lane < kImageWaves && c0 + lane < p.cpi) ? p.chunk_bits[first + c0 + lane] : 0u;
+        const uint32_t word = (lane < WAVES && c0 + lane < p.cpi) ? p.chunk_bits[first + c0 + lane] : 0u;
         const uint32_t incl = wave_incl_scan_dpp(word & kCountMask);
         const uint32_t n = readlane_u32(word, wave) & kCountMask;
         const uint64_t o = bits_before + (readlane_u32(incl, wave) - n);
@@ -1929,8 +1929,8 @@ __global__ __launch_bounds__(64 * kImageWaves) void k_stuff_image_flags(StuffPar
         // the counts of the chunks between this wave's previous chunk and this one: lane j asks for chunk c - 7 + j
         uint32_t between = 0;
         {
-            const bool asks = lane < kImageWaves - 1 && c + (uint32_t)lane >= (uint32_t)(kImageWaves - 1);
-            const uint32_t at = asks ? c - (uint32_t)(kImageWaves - 1) + (uint32_t)lane : c;
+            const bool asks = lane < WAVES - 1 && c + (uint32_t)lane >= (uint32_t)(WAVES - 1);
+            const uint32_t at = asks ? c - (uint32_t)(WAVES - 1) + (uint32_t)lane : c;
             for (;;) {
                 const uint32_t v = __hip_atomic_load(&ff_pub[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (__all((int)((v & kFfValid) != 0))) {
@@ -1943,8 +1943,8 @@ __global__ __launch_bounds__(64 * kImageWaves) void k_stuff_image_flags(StuffPar
         }
         write_chunk<SPEC>(p, S, w, w4, one_pass, stage, img, c, gid, n, o, ff_upto + between, pred8, lane);
         ff_upto += (uint64_t)between + mine;
-        bits_before += readlane_u32(incl, kImageWaves - 1);
-        tail8_before = readlane_u32(word, kImageWaves - 1) >> 24;  // only read when another round follows: then this one was full
+        bits_before += readlane_u32(incl, WAVES - 1);
+        tail8_before = readlane_u32(word, WAVES - 1) >> 24;  // only read when another round follows: then this one was full
     }
 }
 
@@ -2133,10 +2133,17 @@ hipError_t launch_stuff_image(const StuffParams& p, uint32_t n_images, hipStream
     (void)hipGetLastError();
     const dim3 grid(n_images), block(64 * kImageWaves);
     if (p.cpi <= kStuffImageLdsChunks) {  // every chunk's count has its word in the LDS: no barrier per round
-        if (p.spec_depth >= kStuffDepth)
-            hipLaunchKernelGGL((k_stuff_image_flags<kStuffDepth>), grid, block, 0, s, p);
-        else
-            hipLaunchKernelGGL((k_stuff_image_flags<1>), grid, block, 0, s, p);
+        // fewer than 512 images: 16 waves per workgroup, so that 256 images still give every CU 16 waves
+        if (n_images < 512) {
+            if (p.spec_depth >= kStuffDepth)
+                hipLaunchKernelGGL((k_stuff_image_flags<kStuffDepth, 16>), grid, dim3(64 * 16), 0, s, p);
+            else
+                hipLaunchKernelGGL((k_stuff_image_flags<1, 16>), grid, dim3(64 * 16), 0, s, p);
+        } else if (p.spec_depth >= kStuffDepth) {
+            hipLaunchKernelGGL((k_stuff_image_flags<kStuffDepth, kImageWaves>), grid, block, 0, s, p);
+        } else {
+            hipLaunchKernelGGL((k_stuff_image_flags<1, kImageWaves>), grid, block, 0, s, p);
+        }
         return hipGetLastError();
     }
     if (p.spec_depth >= kStuffDepth)

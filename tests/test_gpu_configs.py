@@ -326,6 +326,51 @@ def test_region_modes_give_the_same_stream():
             run(e, name, frames)
 
 
+def test_one_image_per_compute_unit_takes_the_sixteen_wave_stuffing_kernel():
+    """256 to 511 images that fill the compute units in whole turns, of at least 128 chunks each, take the per-image
+    stuffing kernel with 16 waves per workgroup (no barrier per round: every chunk's 0xFF count has a word in the
+    LDS).  256 images of 128 chunks of mixed content: word for word against the same batch coded in two halves
+    (per-chunk kernels), every eighth image against the oracle."""
+    pkg = load_pkg()
+    dev = torch.device("cuda:0")
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    h, w, n = 512, 1024, n_cu
+    rng = np.random.default_rng(256)
+    imgs = np.empty((n, h, w, 3), np.uint8)
+    base = [natural_like(h, w, 3000 + k) for k in range(4)]
+    for i in range(n):
+        kind = i % 4
+        imgs[i] = base[kind]
+        if kind == 1:
+            imgs[i, 100:164] = rng.integers(0, 256, (64, w, 3), dtype=np.uint8)  # a band of noise: long chunks
+        elif kind == 2:
+            imgs[i, :, 512:] = 255  # all-ones bytes
+        elif kind == 3:
+            imgs[i, 8 * (i % 60):8 * (i % 60) + 8] = rng.integers(0, 256, 3, dtype=np.uint8)
+    d_in = torch.from_numpy(imgs).to(dev)
+    cap = pkg.max_words(w, h) // 2
+    outs = []
+    with pkg.JpegTop(stream=torch.cuda.current_stream().cuda_stream) as e:
+        e.set_profiling(True)
+        for a, b in ((0, n), (0, n // 2), (n // 2, n)):
+            d_words = torch.zeros((b - a, cap), dtype=torch.int32, device=dev)
+            d_res = torch.zeros((b - a, 32), dtype=torch.uint8, device=dev)
+            e.encode_batch_device(d_in[a:b].data_ptr(), b - a, w, h, w * 3, h * w * 3, d_words.data_ptr(), cap,
+                                  d_res.data_ptr())
+            torch.cuda.synchronize()
+            times = e.kernel_times(reset=True)
+            assert (times["k_stuff_image"][0] == 1) == (b - a == n) and (times["k_stuff_write"][0] == 1) == (b - a < n)
+            outs.append((d_words.cpu().numpy().view(np.uint32), d_res.cpu().numpy().view(pkg.RESULT_DTYPE).reshape(b - a)))
+    words, res = outs[0]
+    assert all(int(r["status"]) == 0 for r in res)
+    assert res.tobytes() == np.concatenate([outs[1][1], outs[2][1]]).tobytes()
+    assert np.array_equal(words, np.concatenate([outs[1][0], outs[2][0]]))
+    for i in range(0, n, 8):
+        want, r = O.encode(imgs[i])
+        assert int(res[i]["n_full_words"]) == r.n_full_words and int(res[i]["tail_bits"]) == r.tail_bits
+        assert int(res[i]["tail_word"]) == r.tail_word and np.array_equal(words[i, :len(want)], want)
+
+
 def test_many_images_take_the_per_image_stuffing_kernel():
     """From 512 images of at least 32 chunks on, one launch with one workgroup per image does both stuffing steps
     (k_stuff_image).  520 images of 34 chunks (the last one partial) of every kind of content -- natural, noise
