@@ -9,6 +9,9 @@
 //   k_stuff_count    counts the complete 0xFF bytes each chunk owns once its global bit phase is known.
 //   k_stuff_write    shifts every chunk stream to its global position, inserts 0x00 after 0xFF, writes
 //                    the 32-bit words and the end-of-file result.
+//   k_stuff_image(_flags)  both stuffing steps for batches of many images, one workgroup per image: no prefix
+//                    arrays, no scan launches, every chunk stream read once.
+// Calls of a few frames run as one launch of k_encode_chunks whose waves place, stuff and write their own chunks.
 //
 // Reference arithmetic reproduced here (paths relative to the reference tree):
 //   colour      rtl/1_rbg2ycrcb/rgb2ycrcb.sv:29-39, 77-91, 105-135
