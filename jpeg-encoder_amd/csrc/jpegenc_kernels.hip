@@ -1077,7 +1077,8 @@ __device__ __forceinline__ void write_chunk(const StuffParams& p, const uint32_t
             }
             fill += min(1024u, nm - base) + it_ff;
             wave_sync();
-            flush(false, true);
+            // (the chunk's last step leaves everything to the flush behind the loop: one pass over the stage, not two)
+            if (base + 1024 < nm) flush(false, true);
         }
     }
 
