@@ -95,6 +95,22 @@ def test_ragged_sizes_random(enc, hw):
     assert_same(words, res, rgb)
 
 
+@pytest.mark.parametrize("hw", [(8, 8 * 40000), (8 * 40000, 8), (16, 8 * 20001), (8 * 9999, 24)])
+def test_extreme_aspect_ratios(enc, hw):
+    """One block row of 40 000 MCUs (625 chunks, none wraps), a column of 40 000 block rows of one MCU (every lane of
+    every chunk in a row of its own), and two shapes whose chunks straddle rows at every phase: the MCU coordinates of
+    a lane come from the chunk's first MCU by at most one step to the next row only where a row has 64 MCUs or more."""
+    h, w = hw
+    rng = np.random.default_rng(h + 7 * w)
+    rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    # every other 8x8 tile smooth: short and long MCU strings side by side within a chunk
+    ty, tx = np.mgrid[0:h, 0:w]
+    smooth = ((ty // 8 + tx // 8) & 1).astype(bool)
+    rgb[smooth] = (rgb[smooth] >> 5) + 100
+    words, res = enc.encode(rgb)
+    assert_same(words, res, rgb)
+
+
 def test_tiny_last_chunk_shares_its_word(enc):
     """65 MCUs = one full chunk and one of a single flat MCU (18 bits): the image's last word, the one
     reported as tail_word, then mostly belongs to the first chunk (found by tools/fuzz_gpu.py)."""
