@@ -146,6 +146,20 @@ int jpegenc_encode_batch_noalloc(jpegenc_ctx* ctx, const uint8_t* rgb, int n_ima
 int jpegenc_image_coeffs(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int h, ptrdiff_t stride, uint32_t flags,
                          int16_t* coeffs_out);
 
+/* The other half of that probe: the stream from coefficients.  Puts coeffs (the layout jpegenc_image_coeffs
+ * writes: [(by * (w/8) + bx) * 3 + c][k], k in the coders' reading order; values are taken modulo the ports'
+ * 11 bits, cr_huff.sv:18-25) on the coefficient ports of y_huff / cb_huff / cr_huff for every 8x8 block of a
+ * w x h image after rst, and runs everything from there on -- the three coders (cr_huff.sv:176-231, 518-716,
+ * 1317-1486 and the y/cb twins), the interleave (fifo_out.sv:222-266) and the stuffing (ff_checker.sv:96-360)
+ * -- as jpegenc_encode_rgb8 does, with the same device code from the coders on.  This is how the coders' rules
+ * are checked on values that no 8-bit image produces: zero runs ending at positions 30/31 and 46/47
+ * (cr_huff.sv:213-231, cb_huff.sv:238-241), a last coefficient that is not zero, DC differences of 12 bits, and
+ * the AC value -1024, whose size by the rule on bits [9:0] is 0 (cr_huff.sv:1411-1486).  The quantisation
+ * tables of the context play no part (the values are what the quantisers would deliver).  flags:
+ * JPEGENC_HOST_PTRS (blocks) or JPEGENC_DEVICE_PTRS (coeffs 16-byte aligned; enqueues on the context's stream). */
+int jpegenc_encode_coeffs(jpegenc_ctx* ctx, const int16_t* coeffs, int w, int h, uint32_t flags, uint32_t* words_out,
+                          size_t cap_words, jpegenc_result* result);
+
 /* One image cut into n_stripes horizontal stripes of stripe_rows rows (a multiple of 8;
  * n_stripes*stripe_rows == h).  Every stripe is encoded exactly as jpeg_top would encode that
  * w x stripe_rows sub-image after rst -- the restart-interval view of a huge image.  Equivalent to

@@ -20,7 +20,8 @@ namespace jpegenc {
 // rtl/4_huffman/cr_huff.sv:1553-2082.  The RTL's map entries (run 1..14, size 0) -> table entry 0 are
 // reachable only by an AC coefficient of -1024 (size rule on bits [9:0]); coefficients computed from
 // 8-bit pixels satisfy |AC| <= 1021 (|B| <= 1448 luma / 363 chroma, row sums of |T| <= 46344), so on
-// this path a size-0 symbol always is a zero coefficient and those entries stay empty.
+// the pixel path a size-0 symbol always is a zero coefficient and the (run <= 14, size 0) entries stay empty;
+// what the RTL emits for -1024 stands at size 11, where the coefficient-fed entry point finds it.
 void build_htab(uint32_t out[kHtabEntries]) {
     for (int i = 0; i < kHtabEntries; ++i) out[i] = 0;
     for (int eob = 0; eob < 2; ++eob)
@@ -36,6 +37,11 @@ void build_htab(uint32_t out[kHtabEntries]) {
     {
         const int idx = JPEGENC_AC_RUN_CODE[JPEGENC_SYM_EOB];
         out[kHtabEob] = (uint32_t(JPEGENC_AC_LEN[idx]) << 27) | JPEGENC_AC_CODE[idx];
+    }
+    for (int run = 0; run < 16; ++run) {  // -1024: symbol (run, size 0) through the map, no amplitude
+        const int idx = JPEGENC_AC_RUN_CODE[run << 4];
+        for (int eob = 0; eob < 2; ++eob)
+            out[(run << 5) | (eob << 4) | 11] = (uint32_t(JPEGENC_AC_LEN[idx]) << 27) | JPEGENC_AC_CODE[idx];
     }
     for (int s = 0; s < 12; ++s) {
         const uint32_t code = JPEGENC_DC_CODE[s];
@@ -372,7 +378,7 @@ uint32_t next_generation() {
 // single-launch form (whose launch carries a tag of its own, so that enqueued work cannot be replayed).
 int run_group(jpegenc_ctx* ctx, const Workspace& ws, bool timed, const Plan& pl, const uint8_t* rgb, uint32_t n,
               ptrdiff_t stride, ptrdiff_t image_stride, int align, uint32_t* words, size_t cap_words,
-              jpegenc_result* results) {
+              jpegenc_result* results, const int16_t* coeffs = nullptr) {
     const bool prof_was = ctx->profiling;
     if (!timed) ctx->profiling = false;
     struct Restore {
@@ -389,10 +395,11 @@ int run_group(jpegenc_ctx* ctx, const Workspace& ws, bool timed, const Plan& pl,
     ep.n_mcu = pl.n_mcu;
     ep.cpi = cpi;
     ep.flags = ctx->flags;
+    ep.coeffs = coeffs;
     ep.slots = ws.slots;
     ep.chunk_bits = ws.chunk_bits;
     ep.htab = ctx->htab.p;
-    ep.qmul = ctx->quant ? ctx->qmul.p : nullptr;
+    ep.qmul = (ctx->quant && !coeffs) ? ctx->qmul.p : nullptr;
     ep.state = nullptr;
     ep.generation = 0;
     ep.lanes_per_mcu = 1;
@@ -402,8 +409,8 @@ int run_group(jpegenc_ctx* ctx, const Workspace& ws, bool timed, const Plan& pl,
     ep.results = results;
     // A frame or a few (every chunk resident at once), common kernel variant: one launch does it all -- each
     // chunk's wave waits for the counts of the chunks before it, then stuffs and writes its own stream.
-    if (timed && ctx->pipeline != JPEGENC_PIPELINE_SPLIT && uint64_t(n) * cpi <= kSingleLaunchMaxChunks && !ctx->quant &&
-        align >= 8) {
+    if (timed && !coeffs && ctx->pipeline != JPEGENC_PIPELINE_SPLIT && uint64_t(n) * cpi <= kSingleLaunchMaxChunks &&
+        !ctx->quant && align >= 8) {
         ep.stats = nullptr;
         ep.large_regions = 1;
         ep.state = ctx->state.p;
@@ -420,7 +427,13 @@ int run_group(jpegenc_ctx* ctx, const Workspace& ws, bool timed, const Plan& pl,
         HIPCHK(ctx, launch_encode(ep, n, align, ctx->stream));
         return JPEGENC_OK;
     }
-    int rc_regions = choose_regions(ctx, &ep, align, uint64_t(n) * cpi);
+    int rc_regions = JPEGENC_OK;
+    if (coeffs) {  // the coders of the small-region variant unless large regions are asked for; no statistics
+        ep.stats = nullptr;
+        ep.large_regions = ctx->region_mode == JPEGENC_REGIONS_LARGE ? 1u : 0u;
+    } else {
+        rc_regions = choose_regions(ctx, &ep, align, uint64_t(n) * cpi);
+    }
     if (rc_regions != JPEGENC_OK) return rc_regions;
     {
         ProfScope ps(ctx, K_ENCODE);
@@ -465,7 +478,7 @@ int run_group(jpegenc_ctx* ctx, const Workspace& ws, bool timed, const Plan& pl,
     tp.pred_tail8 = 0;
     tp.bit_base = tp.ff_base = tp.out_word_base = 0;
     tp.eof = 1;
-    tp.spec_depth = ctx->quant ? 1u : 5u;
+    tp.spec_depth = (ctx->quant && !coeffs) ? 1u : 5u;
     tp.inline_scan = inline_scan ? 1u : 0u;
     if (per_image) {
         ProfScope ps(ctx, K_STUFF_IMAGE);
@@ -868,6 +881,60 @@ int jpegenc_image_coeffs(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int h, ptr
     return JPEGENC_OK;
 }
 
+int jpegenc_encode_coeffs(jpegenc_ctx* ctx, const int16_t* coeffs, int w, int h, uint32_t flags, uint32_t* words_out,
+                          size_t cap_words, jpegenc_result* result) {
+    if (!ctx || !coeffs || !words_out || !result || cap_words == 0) return JPEGENC_E_BAD_ARG;
+    if (w <= 0 || h <= 0 || (w % 8) || (h % 8)) return JPEGENC_E_BAD_ARG;
+    DevGuard guard(ctx->device);
+    HIPCHK(ctx, guard.err);
+    Plan pl;
+    int rc = make_plan(ctx, 1, w, h, &pl);
+    if (rc != JPEGENC_OK) return rc;
+    ctx->seg_ready = ctx->seg_counted = false;
+    rc = reserve_for_plan(ctx, &pl);
+    if (rc != JPEGENC_OK) return rc;
+    const Workspace ws = ctx_workspace(ctx);
+    if (flags & JPEGENC_DEVICE_PTRS) {
+        if (reinterpret_cast<uintptr_t>(coeffs) & 15u) return JPEGENC_E_BAD_ARG;
+        rc = run_group(ctx, ws, true, pl, nullptr, 1, 0, 0, 8, words_out, cap_words, result, coeffs);
+        if (rc != JPEGENC_OK) return rc;
+        return workspace_used(ctx);
+    }
+    // host memory: staged through buffers of this call's own (a checking aid, not a hot path)
+    const size_t in_bytes = size_t(pl.n_mcu) * 3 * 64 * sizeof(int16_t);
+    DevBuf<uint8_t> in;
+    hipError_t e = in.reserve(in_bytes);
+    if (e == hipSuccess) e = ctx->out_stage.reserve(cap_words);
+    if (e == hipSuccess) e = ctx->res_stage.reserve(1);
+    if (e == hipSuccess) e = hipMemcpyAsync(in.p, coeffs, in_bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        rc = run_group(ctx, ws, true, pl, nullptr, 1, 0, 0, 8, ctx->out_stage.p, cap_words, ctx->res_stage.p,
+                       reinterpret_cast<const int16_t*>(in.p));
+        if (rc == JPEGENC_OK) rc = workspace_used(ctx);
+        if (rc == JPEGENC_OK) {
+            e = hipMemcpyAsync(result, ctx->res_stage.p, sizeof(jpegenc_result), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e == hipSuccess) {
+                uint64_t nw = result->n_full_words + (result->tail_bits ? 1 : 0);
+                if (nw > cap_words) {
+                    nw = cap_words;
+                    rc = JPEGENC_E_TOO_SMALL;
+                }
+                if (nw) e = hipMemcpy(words_out, ctx->out_stage.p, size_t(nw) * 4, hipMemcpyDeviceToHost);
+            }
+        }
+    }
+    (void)hipStreamSynchronize(ctx->stream);  // nothing in flight reads the staging buffer when it goes
+    in.release();
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        ctx->last_error = "device memory exhausted: jpegenc_encode_coeffs staging";
+        return JPEGENC_E_NOMEM;
+    }
+    HIPCHK(ctx, e);
+    return rc;
+}
+
 int jpegenc_encode_rgb8(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int h, ptrdiff_t stride, uint32_t flags,
                         uint32_t* words_out, size_t cap_words, jpegenc_result* result) {
     return jpegenc_encode_batch(ctx, rgb, 1, w, h, stride, stride * ptrdiff_t(h), flags, words_out, cap_words, result);
@@ -924,6 +991,7 @@ int jpegenc_segment_encode(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int rows
     ep.n_mcu = uint32_t(n_mcu64);
     ep.cpi = cpi;
     ep.flags = ctx->flags | (continues ? 4u : 0u);
+    ep.coeffs = nullptr;
     ep.slots = ctx->slots.p;
     ep.chunk_bits = ctx->chunk_bits.p;
     ep.htab = ctx->htab.p;

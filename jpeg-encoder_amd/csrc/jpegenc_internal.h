@@ -41,6 +41,10 @@ hipError_t static_workspace(void** ptr);
 //   size 0..10  AC.  (run <= 14, size 0) is a zero coefficient inside a run: nothing; (run 15, size 0) is
 //               the 16th zero: ZRL in the eob = 0 entries, nothing in the eob = 1 entries
 //               (rtl/4_huffman/cr_huff.sv:558).
+//   size 11     AC value -1024, whose size by the rule on bits [9:0] is 0 (cr_huff.sv:1411-1486): the code the
+//               run/size map gives (run, size 0), no amplitude bits -- EOB's code for run 0, the map's entry 0
+//               for runs 1..14 (cr_huff.sv:2069-2082), ZRL's for run 15, whatever end_of_block says.  Only the
+//               coefficient-fed variant reaches it.
 //   size 14, run 0, eob 0   the EOB code (an AC size never exceeds 10, so sizes 11..15 are free)
 //   size 15, eob 0          the DC code of size `run` (0..11)
 constexpr int kHtabEntries = 512;
@@ -57,6 +61,8 @@ struct EncodeParams {
     uint32_t n_images;     // images of this launch (set by launch_encode)
     uint32_t flags;        // bit 0: rgb wrap quirk, bit 1: cb 6'd64 quirk, bit 2: the images continue a
                            // stream: the DC predictors of their first MCU come from the block row above
+    const int16_t* coeffs;  // nullptr, or (coefficient-fed checking variant, rgb unused) [n_images][n_mcu][3][64]:
+                            // the values at the coders' inputs in their reading order, 16-byte aligned
     uint32_t* slots;       // [n_images * cpi][kSlotWords]
     uint32_t* chunk_bits;  // [n_images * cpi]
     const uint32_t* htab;  // [kHtabEntries]

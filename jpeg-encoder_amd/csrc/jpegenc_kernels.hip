@@ -295,6 +295,12 @@ __device__ __forceinline__ void dct_cols_pairs(const int (&pc)[4][8], int (&tp)[
 // where the coefficient of zig-zag position z sits in tp
 __host__ __device__ constexpr int pair_reg(int z) { return (kZZ[z] & 7) * 4 + (kZZ[z] >> 4); }
 __host__ __device__ constexpr int pair_half(int z) { return (kZZ[z] >> 3) & 1; }
+// zig-zag position of the coefficient at row * 8 + col
+__host__ __device__ constexpr int inv_zz(int pos) {
+    for (int z = 0; z < 64; ++z)
+        if (kZZ[z] == pos) return z;
+    return -1;
+}
 // The ranges of zig-zag positions that the end-of-block tests tell apart: below 16, 16..31, 32..47, 48..63.  True
 // if exactly the listed registers of tp hold a position of range `lower` in the lower half and one of range
 // `upper` in the upper half.
@@ -564,7 +570,12 @@ __device__ __forceinline__ int lead_bits_half(int t2) {
     return lead;
 }
 
-template <bool GUARD, bool MERGE>
+// EXACT: the size rule on bits [9:0] as written (cr_huff.sv:1411-1486), for coefficients that 8-bit pixels cannot
+// produce: an AC value of -1024 has no clear bit among (v - 1)[9:0], so its size is 0 although it is not zero, and
+// the coder emits the table entry of (run, size 0) with no amplitude bits.  The leading-bit count gives such a value
+// size 11, which no other AC value has: the table holds those entries at size 11 (build_htab), and only the
+// amplitude has to go.  Used by the coefficient-fed variant; the variants fed from pixels never meet the value.
+template <bool GUARD, bool MERGE, bool EXACT = false>
 __device__ __forceinline__ void encode_block_pairs(const int (&tp)[32], int dc, int dc_pred, bool cb_eob_quirk,
                                                    const uint32_t* htab, const uint8_t* hlen, uint32_t* priv,
                                                    BitWriter& bw) {
@@ -605,6 +616,7 @@ __device__ __forceinline__ void encode_block_pairs(const int (&tp)[32], int dc, 
         lead = lead_bits_half<pair_half(k)>(t2);
         size = mag_bits(lead);
         amp = __builtin_amdgcn_ubfe((uint32_t)t2, pair_half(k) ? 16u : 0u, size);
+        if constexpr (EXACT) amp = size > 10u ? 0u : amp;
     };
     auto sym_at = [&](auto kc) {
         constexpr int k = decltype(kc)::value;
@@ -1246,9 +1258,12 @@ __device__ __forceinline__ uint32_t fit_range_end(uint32_t need_incl, uint32_t l
 // LPM (lanes per MCU) = 3, single-launch form of calls of at most 2048 x 21 MCUs (one 1080p frame): a lane codes one
 // component block, lane = 3 * MCU + component, 21 MCUs per chunk -- a third of the work per wave and three times
 // the waves, for calls that leave most of the GPU idle otherwise.  The 63 strings concatenate in lane order as ever.
-template <int ALIGN, bool QUANT, bool WRAP, int REGION, bool FUSED, int WAVES, int LPM = 1>
+// COEFFS: the checking variant that takes the coefficients at the coders' inputs (EncodeParams::coeffs) instead of
+// transforming pixels: everything from the coders on is the code of the variant it is built from.
+template <int ALIGN, bool QUANT, bool WRAP, int REGION, bool FUSED, int WAVES, int LPM = 1, bool COEFFS = false>
 __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_encode_chunks(EncodeParams p) {
     static_assert(LPM == 1 || (LPM == 3 && FUSED && !QUANT && ALIGN == 8), "one lane per block exists for the single-launch form only");
+    static_assert(!COEFFS || (!QUANT && !FUSED && LPM == 1), "coefficients feed the coder that reads pairs");
     constexpr int kMcus = LPM == 3 ? 21 : kChunkMcus;  // MCUs per chunk
     constexpr int kRegionWords = REGION;
     constexpr int kOwnWords = kRegionWords - 1;  // first pass: REGION - 2 usable words and one zero word behind them
@@ -1348,7 +1363,13 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
     // (a segment that continues an image, flags bit 2, takes them from the last MCU of the block row above
     // its first row)
     int halo[3] = {0, 0, 0};
-    if (c > 0 || (p.flags & 4u)) {
+    if constexpr (COEFFS) {
+        if (c > 0) {
+            const int16_t* hq = p.coeffs + ((uint64_t)img * p.n_mcu + (b0 - 1u)) * 192u;
+#pragma unroll
+            for (int comp = 0; comp < 3; ++comp) halo[comp] = __builtin_amdgcn_readfirstlane(sext11((int)hq[comp * 64]));
+        }
+    } else if (c > 0 || (p.flags & 4u)) {
         // the MCU before the chunk's first one: left of it, or the last one of the block row above
         const int64_t hy = bx0 ? (int64_t)by0 : (int64_t)by0 - 1;
         const int64_t hx = bx0 ? (int64_t)bx0 - 1 : (int64_t)p.mcu_w - 1;
@@ -1443,8 +1464,29 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
             // registers across the components spills at the register budget of three waves per SIMD,
             // and the scratch traffic then exceeds the saved fetches; with large regions and two waves per SIMD
             // they fit (255 registers), and the kernel is 3 to 12 % slower for it (both measured).
-            uint32_t raw[48];
-            if constexpr (ALIGN == 8) {
+            uint32_t raw[COEFFS ? 1 : 48];
+            if constexpr (COEFFS) {
+                // the block's 64 values, 11-bit ports (cr_huff.sv:18-25), in the coder's reading order -> the pairs
+                // of dct_cols_pairs: tp[4 k + i] = (t of (2 i, k), t of (2 i + 1, k)), k = horizontal frequency
+                const u32x4* q = reinterpret_cast<const u32x4*>(
+                    p.coeffs + ((uint64_t)img * p.n_mcu + min(b, p.n_mcu - 1u)) * 192u + (uint32_t)comp * 64u);
+                uint32_t cw[32];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const u32x4 v = q[i];
+                    cw[4 * i] = v.x; cw[4 * i + 1] = v.y; cw[4 * i + 2] = v.z; cw[4 * i + 3] = v.w;
+                }
+                auto at = [&](int pos) {
+                    const int z = inv_zz(pos);
+                    return sext11((int)(cw[z >> 1] >> (16 * (z & 1))));
+                };
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        tp[4 * k + i] = pk_amp_src((at(16 * i + k) & 0xFFFF) | (at(16 * i + 8 + k) << 16));
+                dc_pair = at(0);
+            } else if constexpr (ALIGN == 8) {
                 if (comp == 2)
                     load_mcu_buf<true>(img_rsrc, lane_off, (int32_t)p.stride, raw);  // the last fetch of these pixels
                 else
@@ -1455,7 +1497,8 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
             // Two separately compiled bodies (shifts are immediates).  The differing asm comments keep
             // the optimiser from folding them back into one body with run-time shift counts.  Each row
             // is converted and transformed before the next one is touched, so the raw pixels die early.
-            if (comp == 0) {
+            if constexpr (COEFFS) {
+            } else if (comp == 0) {
                 int pc[4][8];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -1495,9 +1538,9 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
             const int pred = __builtin_amdgcn_update_dpp(h, dc, 0x138, 0xF, 0xF, false);
             if constexpr (kPairs) {
                 if (!fit)
-                    encode_block_pairs<false, kJoin>(tp, dc, pred, comp == 1 && cb_quirk, htab, hlen, flat, bw);
+                    encode_block_pairs<false, kJoin, COEFFS>(tp, dc, pred, comp == 1 && cb_quirk, htab, hlen, flat, bw);
                 else
-                    encode_block_pairs<true, false>(tp, dc, pred, comp == 1 && cb_quirk, htab, hlen, flat, bw);
+                    encode_block_pairs<true, false, COEFFS>(tp, dc, pred, comp == 1 && cb_quirk, htab, hlen, flat, bw);
             } else {
                 if (!fit)
                     encode_block<false, QUANT, kJoin>(x, pred, comp == 1 && cb_quirk, htab, hlen, flat, bw);
@@ -2064,14 +2107,14 @@ hipError_t static_workspace(void** ptr) {
 // (9 % faster); of the variants for the all-ones tables only the common one with small regions joins them there.
 // (Every launcher first takes any error an earlier, unrelated HIP call has left pending: what it returns is
 // then the outcome of its own launch.)
-template <int ALIGN, bool QUANT, int REGION, bool FUSED = false, int WAVES = 1, int LPM = 1>
+template <int ALIGN, bool QUANT, int REGION, bool FUSED = false, int WAVES = 1, int LPM = 1, bool COEFFS = false>
 static hipError_t launch_encode_b(const EncodeParams& p, dim3 grid, hipStream_t s) {
     (void)hipGetLastError();
     grid.x = (grid.x + WAVES - 1) / WAVES;  // WAVES chunks per workgroup
-    if (p.flags & 1u)
-        hipLaunchKernelGGL((k_encode_chunks<ALIGN, QUANT, true, REGION, FUSED, WAVES, LPM>), grid, dim3(64 * WAVES), 0, s, p);
+    if (COEFFS || (p.flags & 1u))  // (the colour rounder's switch means nothing to the coefficient-fed variant)
+        hipLaunchKernelGGL((k_encode_chunks<ALIGN, QUANT, true, REGION, FUSED, WAVES, LPM, COEFFS>), grid, dim3(64 * WAVES), 0, s, p);
     else
-        hipLaunchKernelGGL((k_encode_chunks<ALIGN, QUANT, false, REGION, FUSED, WAVES, LPM>), grid, dim3(64 * WAVES), 0, s, p);
+        hipLaunchKernelGGL((k_encode_chunks<ALIGN, QUANT, COEFFS, REGION, FUSED, WAVES, LPM, COEFFS>), grid, dim3(64 * WAVES), 0, s, p);
     return hipGetLastError();
 }
 
@@ -2101,6 +2144,13 @@ hipError_t launch_encode(const EncodeParams& p_in, uint32_t n_images, int align,
     const uint32_t nz = (n_images + 65534u) / 65535u;
     if (nz > 65535u) return hipErrorInvalidValue;
     const dim3 grid(p.cpi, ny, nz);
+    if (p.coeffs) {
+        // coefficient-fed checking variants: the coders of the small-region variant (symbols joined) or of the
+        // large-region one (symbol by symbol)
+        if (p.state || p.qmul) return hipErrorInvalidValue;
+        return p.large_regions ? launch_encode_b<8, false, kRegionLarge, false, kLargeWaves, 1, true>(p, grid, s)
+                               : launch_encode_b<8, false, kRegionSmall, false, kSmallWaves, 1, true>(p, grid, s);
+    }
     if (p.state) {
         // single-launch form: only the common variant (a launch this small leaves most of the LDS unused anyway)
         if (p.qmul || align < 8 || chunks > kSingleLaunchMaxChunks) return hipErrorInvalidValue;

@@ -26,7 +26,7 @@ N_KERNELS = 5
 ABI_SYMBOLS = [
     "jpegenc_default_config", "jpegenc_create", "jpegenc_destroy", "jpegenc_set_stream", "jpegenc_synchronize",
     "jpegenc_max_words", "jpegenc_encode_rgb8", "jpegenc_encode_batch", "jpegenc_encode_batch_noalloc",
-    "jpegenc_encode_stripes", "jpegenc_image_coeffs", "jpegenc_reset",
+    "jpegenc_encode_stripes", "jpegenc_image_coeffs", "jpegenc_encode_coeffs", "jpegenc_reset",
     "jpegenc_push_pixel", "jpegenc_push_pixels", "jpegenc_end_of_file", "jpegenc_read_words",
     "jpegenc_words_to_bytes", "jpegenc_set_profiling", "jpegenc_kernel_times", "jpegenc_kernel_name",
     "jpegenc_set_workspace_limit", "jpegenc_set_region_mode", "jpegenc_region_stats", "jpegenc_set_pipeline", "jpegenc_reserve", "jpegenc_segment_encode", "jpegenc_segment_count",
@@ -103,6 +103,7 @@ def load_library(path=None):
     L.jpegenc_set_pipeline.argtypes = [vp, i32]
     L.jpegenc_region_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.jpegenc_image_coeffs.argtypes = [vp, vp, i32, i32, C.c_ssize_t, u32, vp]
+    L.jpegenc_encode_coeffs.argtypes = [vp, vp, i32, i32, u32, vp, sz, vp]
     u64 = C.c_uint64
     L.jpegenc_segment_encode.argtypes = [vp, vp, i32, i32, C.c_ssize_t, u32, C.POINTER(u64), C.POINTER(u32)]
     L.jpegenc_segment_count.argtypes = [vp, u64, u32, C.POINTER(u64)]
@@ -258,6 +259,20 @@ class JpegTop:
         out = np.zeros(((h // 8) * (w // 8), 3, 64), dtype=np.int16)
         self._check(self.lib.jpegenc_image_coeffs(self._ctx, rgb.ctypes.data, w, h, w * 3, HOST_PTRS, out.ctypes.data))
         return out
+
+    def encode_coeffs(self, coeffs, w, h, cap_words=None):
+        """The stream the three Huffman coders, the interleave and the stuffing make of `coeffs` (int16
+        [blocks, 3, 64] as image_coeffs returns them, any 11-bit values) for a w x h image after rst.
+        Returns (words incl. tail word, result record)."""
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.int16)
+        assert coeffs.shape == ((h // 8) * (w // 8), 3, 64)
+        cap = int(cap_words or max_words(w, h))
+        words = np.zeros(cap, dtype=np.uint32)
+        res = np.zeros(1, dtype=RESULT_DTYPE)
+        self._check(self.lib.jpegenc_encode_coeffs(self._ctx, coeffs.ctypes.data, w, h, HOST_PTRS, words.ctypes.data,
+                                                   cap, res.ctypes.data))
+        k = min(cap, int(res[0]["n_full_words"]) + (1 if res[0]["tail_bits"] else 0))
+        return words[:k].copy(), res[0]
 
     # -- raster API (device memory, asynchronous on the context's stream) -------------------
     def encode_batch_device(self, rgb_ptr, n, w, h, stride, image_stride, words_ptr, cap_words, results_ptr):

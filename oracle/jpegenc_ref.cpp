@@ -439,6 +439,25 @@ int ref_image_coeffs(const ref_config* cfg, const uint8_t* rgb, int w, int h, pt
     return encode_image(cfg, rgb, w, h, stride, s, out);
 }
 
+int ref_encode_coeffs(const ref_config* cfg, const int16_t* coeffs, size_t n_mcu, uint32_t* words_out,
+                      size_t cap_words, ref_result* res) {
+    // The three *_huff modules fed directly at their coefficient ports (cr_huff.sv:18-25: 11-bit ports, the
+    // values are wrapped to 11 bits), blocks in feed order, Y then Cb then Cr (fifo_out.sv:195-197, :222-243),
+    // DC predictors cleared by rst before the first block (cr_huff.sv:710), then ff_checker.
+    std::vector<uint8_t> bytes;
+    ByteSink sink;
+    sink.v = &bytes;
+    int32_t pred[3] = {0, 0, 0};
+    int32_t blk[64];
+    for (size_t b = 0; b < n_mcu; ++b)
+        for (int c = 0; c < 3; ++c) {
+            for (int k = 0; k < 64; ++k) blk[kZigzag[k]] = coeffs[(b * 3 + size_t(c)) * 64 + size_t(k)];
+            huff_block(cfg, c, blk, &pred[c], sink);
+        }
+    sink.finish();
+    return stuff_and_pack(bytes, sink.total, words_out, cap_words, res);
+}
+
 // ---- port-level shim (jpeg_top.sv:18-28) --------------------------------------------------------
 struct ref_port {
     ref_config cfg;

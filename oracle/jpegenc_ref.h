@@ -87,6 +87,12 @@ int ref_encode_rgb8_unstuffed(const ref_config* cfg, const uint8_t* rgb, int w, 
 int ref_image_coeffs(const ref_config* cfg, const uint8_t* rgb, int w, int h, ptrdiff_t stride,
                      int16_t* out);
 
+/* The stream from coefficients: coeffs[(b*3+comp)*64 + zz] (the layout ref_image_coeffs writes) are put on
+ * the coefficient ports of y_huff / cb_huff / cr_huff for MCUs b = 0 .. n_mcu-1 after rst, and the bits go
+ * through interleave and stuffing as in ref_encode_rgb8.  Values are wrapped to the ports' 11 bits. */
+int ref_encode_coeffs(const ref_config* cfg, const int16_t* coeffs, size_t n_mcu, uint32_t* words_out,
+                      size_t cap_words, ref_result* res);
+
 /* Port-level shim shaped like jpeg_top: one pixel per call, 64 consecutive pixels = one block. */
 typedef struct ref_port ref_port;
 ref_port* ref_port_open(const ref_config* cfg);

@@ -52,6 +52,8 @@ def lib():
         L.ref_encode_rgb8_unstuffed.argtypes = [C.POINTER(RefConfig), C.c_void_p, C.c_int, C.c_int, C.c_ssize_t,
                                                 C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
         L.ref_image_coeffs.argtypes = [C.POINTER(RefConfig), C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_void_p]
+        L.ref_encode_coeffs.argtypes = [C.POINTER(RefConfig), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                        C.POINTER(RefResult)]
         L.ref_port_open.argtypes = [C.POINTER(RefConfig)]
         L.ref_port_open.restype = C.c_void_p
         L.ref_port_reset.argtypes = [C.c_void_p]
@@ -103,6 +105,22 @@ def image_coeffs(rgb, cfg=None):
     if rc:
         raise RuntimeError("ref_image_coeffs rc=%d" % rc)
     return out
+
+
+def encode_coeffs(coeffs, cfg=None):
+    """coeffs: int16 [n_mcu, 3, 64] in the coders' reading order (what image_coeffs returns).  Returns (words
+    incl. tail word, RefResult) of the stream the three Huffman coders make of them after rst."""
+    cfg = cfg or default_config()
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.int16)
+    n_mcu = coeffs.shape[0]
+    cap = lib().ref_max_words(8, 8 * n_mcu)
+    words = np.zeros(cap, dtype=np.uint32)
+    res = RefResult()
+    rc = lib().ref_encode_coeffs(C.byref(cfg), coeffs.ctypes.data, n_mcu, words.ctypes.data, cap, C.byref(res))
+    if rc:
+        raise RuntimeError("ref_encode_coeffs rc=%d" % rc)
+    n = res.n_full_words + (1 if res.tail_bits else 0)
+    return words[:n].copy(), res
 
 
 def huff_block(blk_huff_order, comp, pred=0, cfg=None):
