@@ -130,7 +130,10 @@ int jpegenc_encode_batch(jpegenc_ctx* ctx, const uint8_t* rgb, int n_images, int
  * (no JPEGENC_PAD_EDGES: padding needs a staging buffer).
  * All calls on one GPU, from every context, share that GPU's array: calls that overlap in time on one GPU
  * (two streams, two contexts, two threads) race.  The array keeps the last call's contents; the kernels
- * rewrite every part they later read, so nothing has to be cleared between calls. */
+ * rewrite every part they later read, so nothing has to be cleared between calls.
+ * Captured into a HIP graph the call leaves kernel launches only (no event, no copy): the graph refers to the
+ * context's tables, so it has to be destroyed before jpegenc_destroy, and it keeps the staging-region size the
+ * context stood at when it was captured (jpegenc_set_region_mode; no statistics are collected by these calls). */
 #define JPEGENC_NOALLOC_MAX_CHUNKS 2048
 int jpegenc_encode_batch_noalloc(jpegenc_ctx* ctx, const uint8_t* rgb, int n_images, int w, int h, ptrdiff_t stride,
                                  ptrdiff_t image_stride, uint32_t* words_out, size_t cap_words_per_image,

@@ -409,17 +409,20 @@ int run_group(jpegenc_ctx* ctx, const Workspace& ws, bool timed, const Plan& pl,
     ep.results = results;
     // A frame or a few (every chunk resident at once), common kernel variant: one launch does it all -- each
     // chunk's wave waits for the counts of the chunks before it, then stuffs and writes its own stream.
-    if (timed && !coeffs && ctx->pipeline != JPEGENC_PIPELINE_SPLIT && uint64_t(n) * cpi <= kSingleLaunchMaxChunks &&
-        !ctx->quant && align >= 8) {
+    // (every chunk's wave has to be resident, eight one-wave workgroups per compute unit: a device with fewer
+    // units than the 256 the limit is named for takes the form for correspondingly smaller calls)
+    const uint64_t resident = std::min<uint64_t>(kSingleLaunchMaxChunks, 8u * uint64_t(std::max(ctx->n_cu, 0)));
+    if (timed && !coeffs && ctx->pipeline != JPEGENC_PIPELINE_SPLIT && uint64_t(n) * cpi <= resident && !ctx->quant &&
+        align >= 8) {
         ep.stats = nullptr;
         ep.large_regions = 1;
         ep.state = ctx->state.p;
         ep.generation = next_generation();
         // about a frame of 1080p or less: a lane per component block, chunks of 21 MCUs -- three times the waves
-        // with a third of the work each, on a GPU that such a call leaves mostly idle (the workspace holds slots
-        // for these chunks too: encode_device has seen to it)
+        // with a third of the work each, on a GPU that such a call leaves mostly idle (these chunks never use
+        // their workspace slots)
         const uint32_t cpi_wide = (pl.n_mcu + kWideChunkMcus - 1) / kWideChunkMcus;
-        if (ctx->pipeline == JPEGENC_PIPELINE_AUTO && uint64_t(n) * cpi_wide <= kSingleLaunchMaxChunks) {
+        if (ctx->pipeline == JPEGENC_PIPELINE_AUTO && uint64_t(n) * cpi_wide <= resident) {
             ep.cpi = cpi_wide;
             ep.lanes_per_mcu = 3;
         }
@@ -431,6 +434,16 @@ int run_group(jpegenc_ctx* ctx, const Workspace& ws, bool timed, const Plan& pl,
     if (coeffs) {  // the coders of the small-region variant unless large regions are asked for; no statistics
         ep.stats = nullptr;
         ep.large_regions = ctx->region_mode == JPEGENC_REGIONS_LARGE ? 1u : 0u;
+    } else if (!timed) {
+        // the call that allocates nothing (possibly under graph capture): the region size the context stands at,
+        // no statistics -- their memset and copy would be replayed with the graph and steer nothing
+        ep.stats = nullptr;
+        ep.large_regions = 0;
+        if (!ctx->quant && align >= 8)
+            ep.large_regions = (ctx->region_mode == JPEGENC_REGIONS_AUTO ? ctx->large_regions
+                                                                         : ctx->region_mode == JPEGENC_REGIONS_LARGE)
+                                   ? 1u
+                                   : 0u;
     } else {
         rc_regions = choose_regions(ctx, &ep, align, uint64_t(n) * cpi);
     }
@@ -512,10 +525,8 @@ int encode_device(jpegenc_ctx* ctx, const uint8_t* rgb, int n_images, int w, int
     ctx->seg_ready = ctx->seg_counted = false;  // whatever a segment call left in the workspace is gone
     rc = reserve_for_plan(ctx, &pl);
     if (rc != JPEGENC_OK) return rc;
-    {   // the single-launch form of the smallest calls cuts an image into more chunks (run_group)
-        const uint64_t wide = uint64_t(n_images) * ((pl.n_mcu + kWideChunkMcus - 1) / kWideChunkMcus);
-        if (wide <= kSingleLaunchMaxChunks) MEMCHK(ctx, reserve_workspace(ctx, size_t(wide)));
-    }
+    // (The single-launch form with a lane per component block cuts an image into three times the chunks, and
+    // needs no slots for them: such a chunk always fits its LDS regions -- a static_assert in the kernel.)
     const Workspace ws = ctx_workspace(ctx);
     const int align = pointer_align(rgb, stride, image_stride, n_images, h);
     for (int first = 0; first < n_images; first += int(pl.sub)) {
@@ -839,8 +850,17 @@ int jpegenc_encode_batch_noalloc(jpegenc_ctx* ctx, const uint8_t* rgb, int n_ima
     rc = run_group(ctx, ws, false, pl, rgb, uint32_t(n_images), stride, image_stride,
                    pointer_align(rgb, stride, image_stride, n_images, h), words_out, cap_words_per_image, results);
     if (rc != JPEGENC_OK) return rc;
-    // the hand-off words and statistics it used are the context's own: a later call on another stream
-    // (jpegenc_set_stream) has to wait for this one like for any other (recording an event allocates nothing)
+    // Outside graph capture the call is ordered like any other (jpegenc_set_stream makes a new stream wait for the
+    // event; recording it allocates nothing).  Under capture nothing is recorded: the event would become part of
+    // the graph, be recorded again by every replay, and a later jpegenc_set_stream would wait on a captured
+    // event.  What a replay touches is the device's static array, not this context's workspace; ordering replays
+    // against other work on the GPU is the caller's business, as the header says.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx->stream, &cap) != hipSuccess) {
+        (void)hipGetLastError();
+        cap = hipStreamCaptureStatusNone;
+    }
+    if (cap != hipStreamCaptureStatusNone) return JPEGENC_OK;
     return workspace_used(ctx);
 }
 

@@ -1290,6 +1290,13 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
     uint32_t* const htab = tables;
     uint8_t* const hlen = reinterpret_cast<uint8_t*>(tables + kHtabEntries);
     static_assert(!FUSED || sizeof(tables) >= kStageBytes, "the stage fits the table's place");
+    // Single-launch form, stream still in the LDS: the stuffing steps read it 1 KB at a time plus one word, also
+    // behind its end -- never behind this wave's part of the LDS.
+    static_assert(!FUSED || ((64 * (REGION - 2) - 1) / 256) * 256 + 4 * 63 + 4 < kPrivWords,
+                  "the last stuffing step's reads stay inside the wave's LDS");
+    // A lane per component block: a block's longest string fits its first-pass region, so such a chunk never takes
+    // the exact-fit passes and never touches its workspace slot (the host reserves none for these chunks).
+    static_assert(LPM != 3 || (kMaxMcuBits / 3) <= (REGION - 2) * 32, "one block always fits its region");
     const int lane = threadIdx.x & 63;
     // grid: x = chunk of the image (WAVES of them per workgroup), y and z = image (no division)
     const uint32_t c = blockIdx.x * WAVES + wave;

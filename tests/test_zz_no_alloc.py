@@ -72,9 +72,12 @@ def test_noalloc_entry_point_matches_the_allocating_one():
         assert (r_ref["status"] == 0).all() and r_new.tobytes() == r_ref.tobytes() and np.array_equal(w_new, w_ref)
 
 
-def test_noalloc_call_replays_from_a_captured_graph():
+@pytest.mark.parametrize("mode", ["auto", "small", "large", "quant"])
+def test_noalloc_call_replays_from_a_captured_graph(mode):
     """The call captured once on a side stream, then replayed three times on other pixels in the same buffers:
-    every replay gives the oracle's words (nothing in the launches is tied to the call that was captured)."""
+    every replay gives the oracle's words (nothing in the launches is tied to the call that was captured).  With
+    the staging-region size chosen by the context or forced, and with quantisation tables; afterwards the context
+    moves to another stream and codes as ever (the capture has left no event behind for it to wait on)."""
     pkg = load_pkg()
     dev = torch.device("cuda:0")
     n, h, w = 3, 264, 520  # 3 x 34 chunks, the last one of an image partial
@@ -89,7 +92,11 @@ def test_noalloc_call_replays_from_a_captured_graph():
     d_res = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
     side = torch.cuda.Stream()
     args = (buf.data_ptr(), n, w, h, w * 3, h * w * 3, d_words.data_ptr(), cap, d_res.data_ptr())
-    with pkg.JpegTop(stream=side.cuda_stream) as e:
+    qtabs = [[3 + (i % 7) for i in range(64)]] * 3 if mode == "quant" else None
+    cfg = O.default_config(qtabs=qtabs)
+    with pkg.JpegTop(stream=side.cuda_stream, qtabs=qtabs) as e:
+        if mode in ("small", "large"):
+            e.set_region_mode(e.REGIONS_SMALL if mode == "small" else e.REGIONS_LARGE)
         e.encode_batch_noalloc(*args)  # once outside capture: code objects loaded, nothing left to set up
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
@@ -106,8 +113,41 @@ def test_noalloc_call_replays_from_a_captured_graph():
             assert (res["status"] == 0).all()
             host = frames.cpu().numpy()
             for i in range(n):
-                want, r = O.encode(host[i])
+                want, r = O.encode(host[i], cfg)
                 k = int(res[i]["n_full_words"]) + (1 if res[i]["tail_bits"] else 0)
                 assert k == len(want) and np.array_equal(d_words[i, :k].cpu().numpy().view(np.uint32), want), i
                 assert int(res[i]["tail_word"]) == r.tail_word
+        # on to another stream and an ordinary call
+        other = torch.cuda.Stream()
+        e.set_stream(other.cuda_stream)
+        d_words.fill_(0)
+        torch.cuda.synchronize()
+        e.encode_batch_device(*args)
+        torch.cuda.synchronize()
+        res = d_res.cpu().numpy().view(pkg.RESULT_DTYPE).reshape(n)
+        want, r = O.encode(buf[0].cpu().numpy(), cfg)
+        assert np.array_equal(d_words[0, :len(want)].cpu().numpy().view(np.uint32), want) and int(res[0]["status"]) == 0
         del graph
+
+
+def test_reserved_calls_allocate_nothing():
+    """After jpegenc_reserve a device-pointer call of at most that size leaves the device's free memory where it
+    was -- the one-frame call included, which runs as a single launch over three times the chunks."""
+    pkg = load_pkg()
+    dev = torch.device("cuda:0")
+    frames = pkg.synth.natural_like_torch(2, 1080, 1920, 31, dev)
+    cap = pkg.max_words(1920, 1080) // 2
+    d_words = torch.zeros((2, cap), dtype=torch.int32, device=dev)
+    d_res = torch.zeros((2, 32), dtype=torch.uint8, device=dev)
+    with pkg.JpegTop(stream=torch.cuda.current_stream().cuda_stream) as e:
+        e.reserve(2, 1920, 1080)
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        for n in (1, 2, 1):
+            e.encode_batch_device(frames.data_ptr(), n, 1920, 1080, 1920 * 3, 1080 * 1920 * 3, d_words.data_ptr(), cap,
+                                  d_res.data_ptr())
+            torch.cuda.synchronize()
+            assert torch.cuda.mem_get_info()[0] == free0
+        res = d_res.cpu().numpy().view(pkg.RESULT_DTYPE).reshape(2)
+        want, r = O.encode(frames[0].cpu().numpy())
+        assert np.array_equal(d_words[0, :len(want)].cpu().numpy().view(np.uint32), want) and int(res[0]["status"]) == 0
