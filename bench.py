@@ -316,14 +316,21 @@ def bench_16k(args, pkg, torch, dist, dev, world, rank, backend):
     if args.mode == "stripes16k":
         mine = pkg.distributed.stripes_of_rank(stripes, rank, world)
         local_img = torch.cat([stripe_pixels(s) for s in mine])  # this rank's stripes, one under the other
-        coder = pkg.distributed.hip_stripe_coder(enc, local_img, len(mine))
+        if backend == "nccl":
+            # one call for all of the rank's stripes; their records reach the host once, gathered
+            resident = pkg.distributed.HipStripes(enc, local_img, len(mine))
 
-        def step():
-            local = {}
-            for k, s in enumerate(mine):
-                wds, res = coder(k)
-                local[s] = (wds.to(xdev), res)
-            return pkg.distributed.gather_stripes(local, stripes, device=xdev)
+            def step():
+                return pkg.distributed.encode_striped_image(resident, stripes, device=xdev)
+        else:
+            coder = pkg.distributed.hip_stripe_coder(enc, local_img, len(mine))
+
+            def step():
+                local = {}
+                for k, s in enumerate(mine):
+                    wds, res = coder(k)
+                    local[s] = (wds.to(xdev), res)
+                return pkg.distributed.gather_stripes(local, stripes, device=xdev)
     else:
         per = stripes // world
         parts = [stripe_pixels(s) for s in range(rank * per, (rank + 1) * per)]
@@ -338,6 +345,9 @@ def bench_16k(args, pkg, torch, dist, dev, world, rank, backend):
                 return fw, wds.to(xdev), res
 
         def step():
+            if backend == "nccl":  # figures and words stay on the GPU; the host waits once, for the gathered spans
+                return pkg.distributed.encode_monolithic(
+                    pkg.distributed.HipBandResident(enc, local_img, lo, lo + per * rows), device=xdev)
             return pkg.distributed.encode_monolithic(Band(enc, local_img, lo, lo + per * rows), device=xdev)
 
     def barrier():

@@ -200,6 +200,25 @@ int jpegenc_segment_count(jpegenc_ctx* ctx, uint64_t bit_offset, uint32_t prev_t
 int jpegenc_segment_write(jpegenc_ctx* ctx, uint64_t ff_offset, int is_last, uint32_t flags, uint32_t* words_out,
                           size_t cap_words, uint64_t* first_word, uint64_t* n_words, jpegenc_result* result);
 
+/* The same three steps for callers that keep the bands' figures on the GPU (several GPUs exchanging them with
+ * device-side collectives): nothing is copied to the host, nothing synchronises, every call only enqueues work on
+ * the context's stream (step 1 may allocate, as above).  All d_* pointers are device memory on the context's
+ * device and must stay valid, and the words the calls read unchanged, until step 3 has run.
+ *   1. jpegenc_segment_encode_dev: d_bits_tail8[0] = the band's bit count, [1] = its last 8 bits.  `flags` as for
+ *      jpegenc_segment_encode (they describe rgb).
+ *   2. jpegenc_segment_count_dev: reads *d_bit_offset and *d_prev_tail8 (the sums and the neighbour's word that
+ *      the caller has worked out on the device), leaves the band's 0xFF count in *d_ff_bytes.
+ *   3. jpegenc_segment_write_dev: reads *d_ff_offset; writes the words to d_words (room for cap_words), d_span[0]
+ *      = first_word, d_span[1] = n_words, and for the last band *d_result.  n_words > cap_words means the band
+ *      did not fit (nothing is written beyond cap_words; the last band's status says so too).
+ * No counterpart in jpeg_top, like the three calls above. */
+int jpegenc_segment_encode_dev(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int rows, ptrdiff_t stride, uint32_t flags,
+                               uint64_t* d_bits_tail8);
+int jpegenc_segment_count_dev(jpegenc_ctx* ctx, const uint64_t* d_bit_offset, const uint64_t* d_prev_tail8,
+                              uint64_t* d_ff_bytes);
+int jpegenc_segment_write_dev(jpegenc_ctx* ctx, const uint64_t* d_ff_offset, int is_last, uint32_t* d_words,
+                              size_t cap_words, uint64_t* d_span, jpegenc_result* d_result);
+
 /* Port-level protocol, one call per clock edge of interest (jpeg_top.sv:20-27):
  *   jpegenc_reset        = rst
  *   jpegenc_push_pixel   = enable with data_in[23:0] = {B[23:16],G[15:8],R[7:0]}; 64 consecutive

@@ -54,6 +54,8 @@ void build_htab(uint32_t out[kHtabEntries]) {
 
 namespace {
 
+enum SegWord { SEG_BITS = 0, SEG_TAIL8, SEG_BIT_OFFSET, SEG_PREV_TAIL8, SEG_FF, SEG_FF_OFFSET, SEG_FIRST_WORD, SEG_N_WORDS, kSegWords };
+
 enum KernelId { K_ENCODE = 0, K_SCAN = 1, K_STUFF_COUNT = 2, K_STUFF_WRITE = 3, K_STUFF_IMAGE = 4 };
 const char* const kKernelNames[JPEGENC_N_KERNELS] = {"k_encode_chunks", "k_scan", "k_stuff_count", "k_stuff_write",
                                                      "k_stuff_image"};
@@ -131,11 +133,15 @@ struct jpegenc_ctx {
     // jpegenc_encode_batch_noalloc: this device's copy of the library's static workspace
     uint8_t* static_ws = nullptr;
 
-    // segment API: what jpegenc_segment_encode left in the workspace
+    // segment API: what jpegenc_segment_encode left in the workspace, and where the band's figures stand in
+    // device memory (the caller's words with the _dev calls, seg_dev with the calls that return them)
     bool seg_ready = false, seg_counted = false;
     uint32_t seg_cpi = 0;
-    uint64_t seg_bits = 0, seg_bit_offset = 0, seg_ff = 0;
-    uint32_t seg_prev_tail8 = 0;
+    const uint64_t* seg_bits_p = nullptr;
+    const uint64_t* seg_bit_offset_p = nullptr;
+    const uint64_t* seg_prev_tail8_p = nullptr;
+    const uint64_t* seg_ff_p = nullptr;
+    DevBuf<uint64_t> seg_dev;  // [kSegWords]: bits, tail8, bit_offset, prev_tail8, ff_bytes, ff_offset, first_word, n_words
 
     // port-level protocol
     std::vector<uint8_t> port_px;
@@ -674,6 +680,7 @@ int jpegenc_create(jpegenc_ctx** out, const jpegenc_config* cfg) {
     e = ctx->htab.reserve(kHtabEntries);
     if (e == hipSuccess) e = ctx->qmul.reserve(3 * 64);
     if (e == hipSuccess) e = ctx->stats.reserve(kEncodeStatsWords);
+    if (e == hipSuccess) e = ctx->seg_dev.reserve(kSegWords);
     if (e == hipSuccess) e = ctx->state.reserve(3 * size_t(kSingleLaunchMaxChunks));
     if (e == hipSuccess) e = hipMemset(ctx->state.p, 0, 3 * size_t(kSingleLaunchMaxChunks) * sizeof(uint64_t));
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&ctx->stats_host), kEncodeStatsWords * 4, hipHostMallocDefault);
@@ -701,6 +708,7 @@ int jpegenc_destroy(jpegenc_ctx* ctx) {
     ctx->qmul.release();
     ctx->stats.release();
     ctx->state.release();
+    ctx->seg_dev.release();
     if (ctx->stats_host) (void)hipHostFree(ctx->stats_host);
     ctx->slots.release();
     ctx->chunk_bits.release();
@@ -971,9 +979,12 @@ int jpegenc_encode_stripes(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int h, p
 }
 
 // ---- one stream from consecutive segments -------------------------------------------------------------
-int jpegenc_segment_encode(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int rows, ptrdiff_t stride, uint32_t flags,
-                           uint64_t* bits, uint32_t* tail8) {
-    if (!ctx || !rgb || !bits || !tail8) return JPEGENC_E_BAD_ARG;
+// The _dev calls only enqueue work: a band's figures (bit count, last 8 bits, 0xFF count, place of its words) are
+// left in device memory and its offsets are read from device memory.  The calls that return those figures are the
+// same launches with the figures in the context's own words, copied back after a stream synchronisation.
+int jpegenc_segment_encode_dev(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int rows, ptrdiff_t stride, uint32_t flags,
+                               uint64_t* d_bits_tail8) {
+    if (!ctx || !rgb || !d_bits_tail8) return JPEGENC_E_BAD_ARG;
     if (w <= 0 || rows <= 0 || (w % 8) || (rows % 8) || stride < ptrdiff_t(w) * 3) return JPEGENC_E_BAD_ARG;
     DevGuard guard(ctx->device);
     HIPCHK(ctx, guard.err);
@@ -1033,20 +1044,31 @@ int jpegenc_segment_encode(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int rows
     sp.counts = ctx->chunk_bits.p;
     sp.prefix = ctx->bit_off.p;
     sp.cpi = cpi;
+    sp.total_out = d_bits_tail8;
+    sp.last_hi8_out = d_bits_tail8 + 1;
     HIPCHK(ctx, launch_scan(sp, 1, ctx->stream));
-    uint32_t last_count = 0;
-    uint64_t last_off = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&last_count, ctx->chunk_bits.p + (cpi - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(&last_off, ctx->bit_off.p + (cpi - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->seg_cpi = cpi;
-    ctx->seg_bits = last_off + (last_count & 0xFFFFFFu);
+    ctx->seg_bits_p = d_bits_tail8;
     ctx->seg_ready = true;
-    *bits = ctx->seg_bits;
-    *tail8 = last_count >> 24;
+    return workspace_used(ctx);
+}
+
+int jpegenc_segment_encode(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int rows, ptrdiff_t stride, uint32_t flags,
+                           uint64_t* bits, uint32_t* tail8) {
+    if (!ctx || !bits || !tail8) return JPEGENC_E_BAD_ARG;
+    const int rc = jpegenc_segment_encode_dev(ctx, rgb, w, rows, stride, flags, ctx->seg_dev.p + SEG_BITS);
+    if (rc != JPEGENC_OK) return rc;
+    DevGuard guard(ctx->device);
+    HIPCHK(ctx, guard.err);
+    uint64_t v[2] = {0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(v, ctx->seg_dev.p + SEG_BITS, sizeof v, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *bits = v[0];
+    *tail8 = uint32_t(v[1]);
     return JPEGENC_OK;
 }
 
+extern "C++" {
 namespace {
 StuffParams segment_params(jpegenc_ctx* ctx) {
     StuffParams tp;
@@ -1060,40 +1082,85 @@ StuffParams segment_params(jpegenc_ctx* ctx) {
     tp.cap_words = 0;
     tp.results = nullptr;
     tp.cpi = ctx->seg_cpi;
-    tp.pred_tail8 = ctx->seg_prev_tail8;
-    tp.bit_base = ctx->seg_bit_offset;
+    tp.pred_tail8 = 0;
+    tp.bit_base = 0;
     tp.ff_base = 0;
     tp.out_word_base = 0;
     tp.eof = 0;
     tp.spec_depth = ctx->quant ? 1u : 5u;
     tp.inline_scan = 0;
+    tp.bit_base_p = ctx->seg_bit_offset_p;
+    tp.pred_tail8_p = ctx->seg_prev_tail8_p;
     return tp;
 }
 }  // namespace
+}  // extern "C++"
+
+int jpegenc_segment_count_dev(jpegenc_ctx* ctx, const uint64_t* d_bit_offset, const uint64_t* d_prev_tail8,
+                              uint64_t* d_ff_bytes) {
+    if (!ctx || !d_bit_offset || !d_prev_tail8 || !d_ff_bytes) return JPEGENC_E_BAD_ARG;
+    if (!ctx->seg_ready) return JPEGENC_E_STATE;
+    DevGuard guard(ctx->device);
+    HIPCHK(ctx, guard.err);
+    ctx->seg_bit_offset_p = d_bit_offset;
+    ctx->seg_prev_tail8_p = d_prev_tail8;
+    ctx->seg_ff_p = d_ff_bytes;
+    const StuffParams tp = segment_params(ctx);
+    HIPCHK(ctx, launch_stuff_count(tp, 1, ctx->stream));
+    ScanParams sp;
+    sp.counts = ctx->chunk_ff.p;
+    sp.prefix = ctx->ff_off.p;
+    sp.cpi = ctx->seg_cpi;
+    sp.total_out = d_ff_bytes;
+    HIPCHK(ctx, launch_scan(sp, 1, ctx->stream));
+    ctx->seg_counted = true;
+    return workspace_used(ctx);
+}
 
 int jpegenc_segment_count(jpegenc_ctx* ctx, uint64_t bit_offset, uint32_t prev_tail8, uint64_t* ff_bytes) {
     if (!ctx || !ff_bytes) return JPEGENC_E_BAD_ARG;
     if (!ctx->seg_ready) return JPEGENC_E_STATE;
     DevGuard guard(ctx->device);
     HIPCHK(ctx, guard.err);
-    ctx->seg_bit_offset = bit_offset;
-    ctx->seg_prev_tail8 = prev_tail8 & 0xFFu;
-    StuffParams tp = segment_params(ctx);
-    HIPCHK(ctx, launch_stuff_count(tp, 1, ctx->stream));
-    ScanParams sp;
-    sp.counts = ctx->chunk_ff.p;
-    sp.prefix = ctx->ff_off.p;
-    sp.cpi = ctx->seg_cpi;
-    HIPCHK(ctx, launch_scan(sp, 1, ctx->stream));
-    uint32_t last_count = 0;
-    uint64_t last_off = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&last_count, ctx->chunk_ff.p + (ctx->seg_cpi - 1), 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(&last_off, ctx->ff_off.p + (ctx->seg_cpi - 1), 8, hipMemcpyDeviceToHost, ctx->stream));
+    const uint64_t in[2] = {bit_offset, uint64_t(prev_tail8 & 0xFFu)};
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (the words may still be read by what an earlier band queued)
+    HIPCHK(ctx, hipMemcpy(ctx->seg_dev.p + SEG_BIT_OFFSET, in, sizeof in, hipMemcpyHostToDevice));
+    const int rc = jpegenc_segment_count_dev(ctx, ctx->seg_dev.p + SEG_BIT_OFFSET, ctx->seg_dev.p + SEG_PREV_TAIL8,
+                                             ctx->seg_dev.p + SEG_FF);
+    if (rc != JPEGENC_OK) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ff_bytes, ctx->seg_dev.p + SEG_FF, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->seg_ff = last_off + last_count;
-    ctx->seg_counted = true;
-    *ff_bytes = ctx->seg_ff;
     return JPEGENC_OK;
+}
+
+int jpegenc_segment_write_dev(jpegenc_ctx* ctx, const uint64_t* d_ff_offset, int is_last, uint32_t* d_words,
+                              size_t cap_words, uint64_t* d_span, jpegenc_result* d_result) {
+    if (!ctx || !d_ff_offset || !d_words || !d_span || cap_words == 0) return JPEGENC_E_BAD_ARG;
+    if (is_last && !d_result) return JPEGENC_E_BAD_ARG;
+    if (!ctx->seg_ready || !ctx->seg_counted) return JPEGENC_E_STATE;
+    DevGuard guard(ctx->device);
+    HIPCHK(ctx, guard.err);
+    // bytes of boundary words that belong to the neighbouring segments stay zero (the span kernel clears the two
+    // words before the write step fills in the band's own bytes): the caller ORs those words
+    SpanParams sp;
+    sp.bit_base = ctx->seg_bit_offset_p;
+    sp.bits = ctx->seg_bits_p;
+    sp.ff_base = d_ff_offset;
+    sp.ff = ctx->seg_ff_p;
+    sp.is_last = is_last ? 1u : 0u;
+    sp.words = d_words;
+    sp.cap_words = cap_words;
+    sp.span = d_span;
+    HIPCHK(ctx, launch_segment_span(sp, ctx->stream));
+    StuffParams tp = segment_params(ctx);
+    tp.words_out = d_words;
+    tp.cap_words = cap_words;
+    tp.results = d_result;
+    tp.ff_base_p = d_ff_offset;
+    tp.eof = is_last ? 1u : 0u;
+    HIPCHK(ctx, launch_stuff_write(tp, 1, ctx->stream));
+    ctx->seg_ready = ctx->seg_counted = false;
+    return workspace_used(ctx);
 }
 
 int jpegenc_segment_write(jpegenc_ctx* ctx, uint64_t ff_offset, int is_last, uint32_t flags, uint32_t* words_out,
@@ -1103,37 +1170,28 @@ int jpegenc_segment_write(jpegenc_ctx* ctx, uint64_t ff_offset, int is_last, uin
     if (!ctx->seg_ready || !ctx->seg_counted) return JPEGENC_E_STATE;
     DevGuard guard(ctx->device);
     HIPCHK(ctx, guard.err);
-    const uint64_t o = ctx->seg_bit_offset, end_bits = o + ctx->seg_bits;
-    const uint64_t pos0 = (o >> 3) + ff_offset;
-    const uint64_t end_pos = (end_bits >> 3) + ff_offset + ctx->seg_ff;  // stuffed bytes of the whole stream so far
-    const uint64_t fw = pos0 >> 2;
-    const uint64_t end_word = is_last ? ((end_pos * 8 + (end_bits & 7u) + 31u) >> 5) : ((end_pos + 3u) >> 2);
-    *first_word = fw;
-    *n_words = end_word - fw;
-    const size_t n_store = size_t(std::min<uint64_t>(*n_words, cap_words));
     uint32_t* d_words = words_out;
     if (!(flags & JPEGENC_DEVICE_PTRS)) {
         MEMCHK(ctx, ctx->out_stage.reserve(cap_words));
         d_words = ctx->out_stage.p;
     }
     MEMCHK(ctx, ctx->res_stage.reserve(1));
-    // bytes of boundary words that belong to the neighbouring segments stay zero: the caller ORs those words
-    HIPCHK(ctx, hipMemsetAsync(d_words, 0, n_store * 4, ctx->stream));
-    StuffParams tp = segment_params(ctx);
-    tp.words_out = d_words;
-    tp.cap_words = cap_words;
-    tp.results = ctx->res_stage.p;
-    tp.ff_base = ff_offset;
-    tp.out_word_base = fw;
-    tp.eof = is_last ? 1u : 0u;
-    HIPCHK(ctx, launch_stuff_write(tp, 1, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(ctx->seg_dev.p + SEG_FF_OFFSET, &ff_offset, 8, hipMemcpyHostToDevice));
+    const int rc = jpegenc_segment_write_dev(ctx, ctx->seg_dev.p + SEG_FF_OFFSET, is_last, d_words, cap_words,
+                                             ctx->seg_dev.p + SEG_FIRST_WORD, ctx->res_stage.p);
+    if (rc != JPEGENC_OK) return rc;
+    uint64_t span[2] = {0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(span, ctx->seg_dev.p + SEG_FIRST_WORD, sizeof span, hipMemcpyDeviceToHost, ctx->stream));
     if (is_last)
         HIPCHK(ctx, hipMemcpyAsync(result, ctx->res_stage.p, sizeof(jpegenc_result), hipMemcpyDeviceToHost, ctx->stream));
-    if (!(flags & JPEGENC_DEVICE_PTRS) && n_store)
-        HIPCHK(ctx, hipMemcpyAsync(words_out, d_words, n_store * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->seg_ready = ctx->seg_counted = false;
-    return (*n_words > cap_words) ? JPEGENC_E_TOO_SMALL : JPEGENC_OK;
+    *first_word = span[0];
+    *n_words = span[1];
+    const size_t n_store = size_t(std::min<uint64_t>(span[1], cap_words));
+    if (!(flags & JPEGENC_DEVICE_PTRS) && n_store)
+        HIPCHK(ctx, hipMemcpy(words_out, d_words, n_store * 4, hipMemcpyDeviceToHost));
+    return (span[1] > cap_words) ? JPEGENC_E_TOO_SMALL : JPEGENC_OK;
 }
 
 int jpegenc_reset(jpegenc_ctx* ctx) {

@@ -93,6 +93,10 @@ struct ScanParams {
     const uint32_t* counts;  // [n_images][cpi]
     uint64_t* prefix;        // [n_images][cpi] exclusive
     uint32_t cpi;
+    // one-image launches of the segment calls: where to leave the sum of the counts and the high byte of the last
+    // count word (a chunk's last 8 bits travel there); nullptr otherwise
+    uint64_t* total_out = nullptr;
+    uint64_t* last_hi8_out = nullptr;
 };
 
 struct StuffParams {
@@ -114,6 +118,13 @@ struct StuffParams {
     uint64_t ff_base;
     uint64_t out_word_base;
     uint32_t eof;
+    // The same three from device memory (k_stuff_count and k_stuff_write only; nullptr: the values above): a
+    // band's place in the whole stream is known on the device first, when the ranks' counts have been gathered,
+    // and need not travel through the host.  With ff_base_p the word that words_out[0] stands for follows too:
+    // out_word_base = ((bit_base >> 3) + ff_base) >> 2.
+    const uint64_t* bit_base_p = nullptr;
+    const uint64_t* pred_tail8_p = nullptr;
+    const uint64_t* ff_base_p = nullptr;
     // How many 1 KB steps of a chunk the stuffing kernels request before they know its length: 5 (all of a
     // photographic chunk at the all-ones tables, 4.4 KB) or 1 (quantised content); selects the kernel variant.
     uint32_t spec_depth;
@@ -134,6 +145,20 @@ hipError_t launch_stuff_write(const StuffParams& p, uint32_t n_images, hipStream
 constexpr uint32_t kStuffImageLdsChunks = 4096;
 // count + write of whole images in one launch (one workgroup per image; for batches of many images)
 hipError_t launch_stuff_image(const StuffParams& p, uint32_t n_images, hipStream_t s);
+
+// Where a band's words lie in the whole stream (first word, word count -> span[0], span[1]), from device-resident
+// figures; also clears the band's first and last word, whose bytes outside the band the write step leaves alone.
+struct SpanParams {
+    const uint64_t* bit_base;  // bits of the stream before the band
+    const uint64_t* bits;      // of the band
+    const uint64_t* ff_base;   // 0xFF bytes before the band
+    const uint64_t* ff;        // owned by the band
+    uint32_t is_last;
+    uint32_t* words;
+    uint64_t cap_words;
+    uint64_t* span;
+};
+hipError_t launch_segment_span(const SpanParams& p, hipStream_t s);
 
 hipError_t launch_pad_edges(const uint8_t* src, int64_t stride, int64_t image_stride, int w, int h, int n_images,
                             uint8_t* dst, hipStream_t s);

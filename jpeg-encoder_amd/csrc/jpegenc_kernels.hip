@@ -1811,6 +1811,44 @@ __global__ __launch_bounds__(256) void k_scan(ScanParams p) {
         out[i] = run;
         run += in[i] & kCountMask;
     }
+    if (threadIdx.x == 255 && img == 0) {  // the last thread's range ends at cpi: its running sum is the total
+        if (p.total_out) *p.total_out = run;
+        if (p.last_hi8_out) *p.last_hi8_out = in[p.cpi - 1] >> 24;
+    }
+}
+
+// The place of a band in the whole stream: see SpanParams.
+__global__ void k_segment_span(SpanParams p) {
+    const uint64_t o = *p.bit_base, end_bits = o + *p.bits;
+    const uint64_t pos0 = (o >> 3) + *p.ff_base;
+    const uint64_t end_pos = (end_bits >> 3) + *p.ff_base + *p.ff;  // stuffed bytes of the whole stream so far
+    const uint64_t fw = pos0 >> 2;
+    const uint64_t end_word = p.is_last ? ((end_pos * 8 + (end_bits & 7u) + 31u) >> 5) : ((end_pos + 3u) >> 2);
+    const uint64_t n = end_word - fw;
+    p.span[0] = fw;
+    p.span[1] = n;
+    if (p.cap_words) p.words[0] = 0u;
+    if (n && n - 1 < p.cap_words) p.words[n - 1] = 0u;
+}
+
+hipError_t launch_segment_span(const SpanParams& p, hipStream_t s) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_segment_span, dim3(1), dim3(1), 0, s, p);
+    return hipGetLastError();
+}
+
+// The stuffing parameters with a band's place taken from device memory where the host has left pointers.
+__device__ __forceinline__ StuffParams with_device_bases(const StuffParams& p) {
+    StuffParams q = p;
+    if (p.bit_base_p) {
+        q.bit_base = *p.bit_base_p;
+        q.pred_tail8 = (uint32_t)*p.pred_tail8_p & 0xFFu;
+    }
+    if (p.ff_base_p) {
+        q.ff_base = *p.ff_base_p;
+        q.out_word_base = ((q.bit_base >> 3) + q.ff_base) >> 2;
+    }
+    return q;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1837,7 +1875,8 @@ __device__ __forceinline__ uint32_t wave_sum_before(const uint32_t* counts, uint
 }
 
 template <int SPEC>  // 1 KB steps requested before the chunk's length is known
-__global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_count(StuffParams p, uint32_t n_chunks) {
+__global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_count(StuffParams p_in, uint32_t n_chunks) {
+    const StuffParams p = with_device_bases(p_in);
     const int lane = threadIdx.x & 63;
     const uint32_t gid = blockIdx.x * kStuffWaves + (threadIdx.x >> 6);
     if (gid >= n_chunks) return;
@@ -1872,7 +1911,8 @@ __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_count(StuffParams p,
 // stored one by one.
 // ------------------------------------------------------------------------------------------------
 template <int SPEC>
-__global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_write(StuffParams p, uint32_t n_chunks) {
+__global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_write(StuffParams p_in, uint32_t n_chunks) {
+    const StuffParams p = with_device_bases(p_in);
     __shared__ __attribute__((aligned(16))) uint8_t stage_all[kStuffWaves][kStageBytes];
     uint8_t* const stage = stage_all[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;

@@ -85,12 +85,70 @@ def gather_stripes(local, n_stripes, device=None, root=0, group=None):
 
 
 def encode_striped_image(encode_stripe, n_stripes, device=None, root=0, group=None):
-    """encode_stripe(s) -> (words tensor, result mapping) for stripe s; encodes this rank's stripes and
-    gathers the container on root."""
+    """Encodes this rank's stripes and gathers the container on root.  `encode_stripe` is either a function
+    encode_stripe(s) -> (words tensor, result mapping) for stripe s, or a coder with
+    encode_all() -> (words, results): all of the rank's stripes in one go, stripe stripes_of_rank(...)[k] in row k
+    of the (n_local, cap) int32 tensor `words`, its 32-byte result record in row k of the (n_local, 32) uint8
+    tensor `results`, both still on `device` -- then the records reach the host once, after they have been
+    gathered (`gather_stripes_resident`)."""
     import torch.distributed as dist
+    if hasattr(encode_stripe, "encode_all"):
+        words, results = encode_stripe.encode_all()
+        return gather_stripes_resident(words, results, n_stripes, device=device, root=root, group=group)
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     local = {s: encode_stripe(s) for s in stripes_of_rank(n_stripes, rank, world)}
     return gather_stripes(local, n_stripes, device=device, root=root, group=group)
+
+
+def gather_stripes_resident(words, results, n_stripes, device=None, root=0, group=None):
+    """gather_stripes for stripes whose words and result records are still where they were coded (see
+    encode_striped_image): one all_gather of the raw records, one copy of the gathered table to the host -- the
+    only point where the host waits for the coder -- then the grouped send/recv of the payloads.  Same return
+    value as gather_stripes."""
+    import torch
+    import torch.distributed as dist
+    from .encoder import RESULT_DTYPE
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = device if device is not None else torch.device("cpu")
+    mine = stripes_of_rank(n_stripes, rank, world)
+    per = (n_stripes + world - 1) // world
+    rec = torch.zeros((per, 32), dtype=torch.uint8, device=dev)
+    rec[:len(mine)] = results.reshape(len(mine), 32)
+    if world > 1:
+        parts = [torch.empty_like(rec) for _ in range(world)]
+        dist.all_gather(parts, rec, group=group)
+        every = torch.stack(parts)
+    else:
+        every = rec[None]
+    every = every.cpu().numpy().view(RESULT_DTYPE).reshape(world, per)  # the host waits here, once
+    recs = [every[s % world, s // world] for s in range(n_stripes)]
+    bad = [s for s in range(n_stripes) if int(recs[s]["status"]) != 0]
+    if bad:
+        raise RuntimeError("stripes %s do not fit their %d words" % (bad, words.shape[1]))
+    n_words = np.array([int(r["n_full_words"]) + (1 if r["tail_bits"] else 0) for r in recs], dtype=np.int64)
+    offsets = np.concatenate([[0], np.cumsum(n_words)]).astype(np.int64)
+    ops, payload = [], None
+    if rank == root:
+        payload = torch.empty(int(offsets[-1]), dtype=torch.int32, device=dev)
+        for s in range(n_stripes):
+            view = payload[int(offsets[s]):int(offsets[s + 1])]
+            if s % world == root:
+                view.copy_(words[s // world, :int(n_words[s])].view(torch.int32))
+            elif view.numel():
+                ops.append(dist.P2POp(dist.irecv, view, s % world, group=group, tag=s))
+    else:
+        for k, s in enumerate(mine):
+            if n_words[s]:
+                ops.append(dist.P2POp(dist.isend, words[k, :int(n_words[s])].view(torch.int32), root, group=group, tag=s))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    if rank != root:
+        return None, None
+    table = np.array([[int(offsets[s])] + [int(recs[s][f]) for f in STRIPE_FIELDS[:-1]] + [int(n_words[s])]
+                      for s in range(n_stripes)], dtype=np.int64)
+    return table, payload
 
 
 def band_rows(h, rank, world):
@@ -113,6 +171,8 @@ def encode_monolithic(band, device=None, root=0, group=None):
     (None, None)."""
     import torch
     import torch.distributed as dist
+    if getattr(band, "device_resident", False):
+        return encode_monolithic_resident(band, device=device, root=root, group=group)
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = device if device is not None else torch.device("cpu")
@@ -167,6 +227,72 @@ def encode_monolithic(band, device=None, root=0, group=None):
     return out, result
 
 
+def encode_monolithic_resident(band, device=None, root=0, group=None):
+    """encode_monolithic for a band coder that keeps its figures where it computes them (`band.device_resident`):
+        band.encode() -> int64 tensor [bits, tail8] on `device`
+        band.count(bit_offset, prev_tail8) -> int64 tensor [ff_bytes]      (arguments: one-element int64 tensors)
+        band.write(ff_offset, is_last) -> (int64 tensor [first_word, n_words], uint8 tensor of the 32-byte result
+                                           record, int32 tensor of words with room to spare)
+    The offsets are sums over the gathered tensors, taken on `device`; the host sees nothing until the bands'
+    spans have been gathered and it has to size the receives -- one wait per image instead of one per phase."""
+    import torch
+    import torch.distributed as dist
+    from .encoder import RESULT_DTYPE
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = device if device is not None else torch.device("cpu")
+
+    def gather(t):
+        if world == 1:
+            return t[None]
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t.contiguous(), group=group)
+        return torch.stack(parts)
+
+    rows = gather(band.encode())                                  # [world, 2]
+    bit_offset = rows[:rank, 0].sum().reshape(1)
+    prev_tail = rows[rank - 1, 1].reshape(1) if rank else torch.zeros(1, dtype=torch.int64, device=dev)
+    ff = gather(band.count(bit_offset, prev_tail))                # [world, 1]
+    span, rec, words = band.write(ff[:rank, 0].sum().reshape(1), rank == world - 1)
+    room = torch.tensor([words.numel()], dtype=torch.int64).to(dev)
+    packed = gather(torch.cat([span.view(torch.uint8), room.view(torch.uint8), rec.view(torch.uint8)]))  # [world, 24 + 32]
+    packed = packed.cpu().numpy()                                 # the host waits here, once
+    spans = packed[:, :24].copy().view(np.int64).reshape(world, 3)
+    last = packed[world - 1, 24:].copy().view(RESULT_DTYPE)[0]
+    if int((spans[:, 1] > spans[:, 2]).any()):  # (every rank sees every band's figures: all raise or none)
+        raise RuntimeError("bands %s do not fit their words" % np.nonzero(spans[:, 1] > spans[:, 2])[0].tolist())
+    words = words[:int(spans[rank, 1])].view(torch.int32)
+    total = int((spans[:, 0] + spans[:, 1]).max())
+    ops, parts = [], {}
+    if rank == root:
+        for r in range(world):
+            if r == root:
+                parts[r] = words
+            else:
+                parts[r] = torch.empty(int(spans[r, 1]), dtype=torch.int32, device=dev)
+                if parts[r].numel():
+                    ops.append(dist.P2POp(dist.irecv, parts[r], r, group=group, tag=r))
+    elif words.numel():
+        ops.append(dist.P2POp(dist.isend, words.contiguous(), root, group=group, tag=rank))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    if rank != root:
+        return None, None
+    if world == 1:
+        out = words  # one band: its words are the stream
+    else:
+        out = torch.zeros(total, dtype=torch.int32, device=dev)
+        for r in range(world):  # neighbouring bands share their boundary words: each wrote only its own bytes
+            a = int(spans[r, 0])
+            out[a:a + parts[r].numel()] |= parts[r]
+    result = {k: int(last[k]) for k in ("n_full_words", "total_bits_unstuffed", "total_bytes_stuffed", "tail_word",
+                                        "tail_bits", "eof_partial_ready", "status")}
+    if result["tail_bits"]:  # the tail word may be shared with the band before the last: take it from the merged words
+        result["tail_word"] = int(out[result["n_full_words"]].item()) & 0xFFFFFFFF
+    return out, result
+
+
 # ---- the HIP path behind the functions above: device-resident images, torch tensors in and out ------------
 def hip_stripe_coder(enc, image, n_stripes, bytes_per_pixel_room=3.0):
     """Returns encode_stripe(s) for `encode_striped_image`: stripe s of `image` (an (h, w, 3) uint8 torch
@@ -192,6 +318,69 @@ def hip_stripe_coder(enc, image, n_stripes, bytes_per_pixel_room=3.0):
         return words[:n], res
 
     return encode_stripe
+
+
+class HipStripes:
+    """Coder for `encode_striped_image` on the HIP path: this rank's stripes, one under the other in `local_img`
+    (an (n_local * rows, w, 3) uint8 torch tensor on the encoder's GPU), coded by ONE jpegenc_encode_batch call
+    (every stripe an image of its own: as jpeg_top codes that sub-image after rst); words and result records stay
+    on the GPU.  `enc`: a JpegTop whose stream is torch's current one."""
+
+    def __init__(self, enc, local_img, n_local, bytes_per_pixel_room=3.0):
+        import torch
+        h, w, _ = local_img.shape
+        self.rows = h // n_local
+        assert self.rows * n_local == h and self.rows % 8 == 0 and local_img.is_contiguous() and local_img.dtype == torch.uint8
+        self.enc, self.img, self.n, self.w = enc, local_img, n_local, w
+        self.cap = int(w * self.rows * bytes_per_pixel_room) // 4 + 2
+        enc.reserve(n_local, w, self.rows)
+
+    def encode_all(self):
+        import torch
+        words = torch.empty((self.n, self.cap), dtype=torch.int32, device=self.img.device)
+        res = torch.empty((self.n, 32), dtype=torch.uint8, device=self.img.device)
+        self.enc.encode_batch_device(self.img.data_ptr(), self.n, self.w, self.rows, self.w * 3, self.rows * self.w * 3,
+                                     words.data_ptr(), self.cap, res.data_ptr())
+        return words, res
+
+
+class HipBandResident:
+    """Band coder for `encode_monolithic` on the HIP path that never waits for the GPU: rows [lo, hi) of `image`
+    through the three device-resident segment calls of the C ABI; bit counts, offsets, spans and words are torch
+    tensors on the encoder's GPU.  `enc`: a JpegTop whose stream is torch's current one, so that the library's
+    launches and torch's small tensor operations run in the order they are issued."""
+    device_resident = True
+
+    def __init__(self, enc, image, lo, hi, bytes_per_pixel_room=3.0):
+        import torch
+        assert image.is_contiguous() and image.dtype == torch.uint8 and lo % 8 == 0 and hi % 8 == 0
+        self.enc, self.image, self.lo, self.hi = enc, image, lo, hi
+        self.w = image.shape[1]
+        self.cap = int(self.w * (hi - lo) * bytes_per_pixel_room) // 4 + 4
+        # bits, tail8 | bit_offset, prev_tail8 | ff_bytes | ff_offset | first_word, n_words
+        self.fig = torch.zeros(8, dtype=torch.int64, device=image.device)
+        self.rec = torch.zeros(32, dtype=torch.uint8, device=image.device)
+
+    def _at(self, i):
+        return self.fig.data_ptr() + 8 * i
+
+    def encode(self):
+        self.enc.segment_encode_dev(self.image.data_ptr() + self.lo * self.w * 3, self.w, self.hi - self.lo, self.w * 3,
+                                    self.lo > 0, self._at(0))
+        return self.fig[0:2]
+
+    def count(self, bit_offset, prev_tail8):
+        self.fig[2:3].copy_(bit_offset)
+        self.fig[3:4].copy_(prev_tail8)
+        self.enc.segment_count_dev(self._at(2), self._at(3), self._at(4))
+        return self.fig[4:5]
+
+    def write(self, ff_offset, is_last):
+        import torch
+        self.fig[5:6].copy_(ff_offset)
+        words = torch.empty(self.cap, dtype=torch.int32, device=self.image.device)
+        self.enc.segment_write_dev(self._at(5), is_last, words.data_ptr(), self.cap, self._at(6), self.rec.data_ptr())
+        return self.fig[6:8], self.rec, words
 
 
 class HipBand:

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "jpegenc_push_pixel", "jpegenc_push_pixels", "jpegenc_end_of_file", "jpegenc_read_words",
     "jpegenc_words_to_bytes", "jpegenc_set_profiling", "jpegenc_kernel_times", "jpegenc_kernel_name",
     "jpegenc_set_workspace_limit", "jpegenc_set_region_mode", "jpegenc_region_stats", "jpegenc_set_pipeline", "jpegenc_reserve", "jpegenc_segment_encode", "jpegenc_segment_count",
-    "jpegenc_segment_write", "jpegenc_strerror", "jpegenc_last_error", "jpegenc_version",
+    "jpegenc_segment_write", "jpegenc_segment_encode_dev", "jpegenc_segment_count_dev", "jpegenc_segment_write_dev", "jpegenc_strerror", "jpegenc_last_error", "jpegenc_version",
 ]
 
 
@@ -108,6 +108,9 @@ def load_library(path=None):
     L.jpegenc_segment_encode.argtypes = [vp, vp, i32, i32, C.c_ssize_t, u32, C.POINTER(u64), C.POINTER(u32)]
     L.jpegenc_segment_count.argtypes = [vp, u64, u32, C.POINTER(u64)]
     L.jpegenc_segment_write.argtypes = [vp, u64, i32, u32, vp, sz, C.POINTER(u64), C.POINTER(u64), C.POINTER(Result)]
+    L.jpegenc_segment_encode_dev.argtypes = [vp, vp, i32, i32, C.c_ssize_t, u32, vp]
+    L.jpegenc_segment_count_dev.argtypes = [vp, vp, vp, vp]
+    L.jpegenc_segment_write_dev.argtypes = [vp, vp, i32, vp, sz, vp, vp]
     L.jpegenc_strerror.argtypes = [i32]
     L.jpegenc_strerror.restype = C.c_char_p
     L.jpegenc_last_error.argtypes = [vp]
@@ -351,6 +354,24 @@ class JpegTop:
             C.memmove(rec.ctypes.data, C.byref(res), 32)
             rec = rec[0]
         return int(fw.value), int(nw.value), rec
+
+    # the same three steps with every figure left in and read from device memory: only enqueue work
+    def segment_encode_dev(self, rgb_ptr, w, rows, stride, continues, bits_tail8_ptr):
+        """bits_tail8_ptr: device address of two uint64 (bit count, last 8 bits)."""
+        self._check(self.lib.jpegenc_segment_encode_dev(self._ctx, C.c_void_p(rgb_ptr), w, rows, stride,
+                                                        DEVICE_PTRS | (SEG_CONTINUES if continues else 0),
+                                                        C.c_void_p(bits_tail8_ptr)))
+
+    def segment_count_dev(self, bit_offset_ptr, prev_tail8_ptr, ff_bytes_ptr):
+        """Device addresses of one uint64 each: two read, one written."""
+        self._check(self.lib.jpegenc_segment_count_dev(self._ctx, C.c_void_p(bit_offset_ptr), C.c_void_p(prev_tail8_ptr),
+                                                       C.c_void_p(ff_bytes_ptr)))
+
+    def segment_write_dev(self, ff_offset_ptr, is_last, words_ptr, cap_words, span_ptr, result_ptr):
+        """span_ptr: device address of two uint64 (first_word, n_words); result_ptr: of a 32-byte result record."""
+        self._check(self.lib.jpegenc_segment_write_dev(self._ctx, C.c_void_p(ff_offset_ptr), int(bool(is_last)),
+                                                       C.c_void_p(words_ptr), cap_words, C.c_void_p(span_ptr),
+                                                       C.c_void_p(result_ptr)))
 
     # -- port-level protocol -----------------------------------------------------------------
     def reset(self):

@@ -199,3 +199,34 @@ class OracleBand:
         if is_last:
             result["tail_word"] = int(words[result["n_full_words"] - first_word]) if result["tail_bits"] else 0
         return first_word, words, result
+
+
+class OracleBandResident:
+    """OracleBand behind the protocol of a band coder that keeps its figures in tensors (CPU tensors here):
+    what `encode_monolithic_resident` drives on the GPUs with the device-resident segment calls."""
+    device_resident = True
+
+    def __init__(self, image, lo, hi, cfg=None):
+        self.band = OracleBand(image, lo, hi, cfg)
+
+    def encode(self):
+        import torch
+        return torch.tensor(self.band.encode(), dtype=torch.int64)
+
+    def count(self, bit_offset, prev_tail8):
+        import torch
+        return torch.tensor([self.band.count(int(bit_offset.item()), int(prev_tail8.item()))], dtype=torch.int64)
+
+    def write(self, ff_offset, is_last):
+        import torch
+        first_word, words, result = self.band.write(int(ff_offset.item()), is_last)
+        rec = np.zeros(32, dtype=np.uint8)
+        if result is not None:
+            r = np.zeros(1, dtype=[("n_full_words", "<u8"), ("total_bits_unstuffed", "<u8"), ("total_bytes_stuffed", "<u8"),
+                                   ("tail_word", "<u4"), ("tail_bits", "u1"), ("eof_partial_ready", "u1"), ("status", "<i2")])
+            for k in r.dtype.names:
+                r[0][k] = result[k]
+            rec = r.view(np.uint8).copy()
+        room = np.zeros(len(words) + 5, dtype=np.int32)  # words with room to spare, as the GPU coder returns them
+        room[:len(words)] = np.asarray(words, dtype=np.uint32).view(np.int32)
+        return (torch.tensor([first_word, len(words)], dtype=torch.int64), torch.from_numpy(rec), torch.from_numpy(room))

@@ -45,6 +45,40 @@ def worker(rank, world, port, mode, out_dir):
                 np.save(os.path.join(out_dir, "payload.npy"), payload.numpy().view(np.uint32))
             else:
                 assert table is None and payload is None
+        elif mode == "stripes_resident":
+            # the coder hands over all of the rank's stripes at once, records unread: what the HIP path does
+            img = natural_like(96, 72, 5)
+            n_stripes, rows = 4, 24
+
+            class Coder:
+                def encode_all(self):
+                    mine = pkg.distributed.stripes_of_rank(n_stripes, rank, world)
+                    words = torch.full((len(mine), 4000), 0x5A5A5A5A, dtype=torch.int32)
+                    recs = np.zeros(len(mine), dtype=pkg.RESULT_DTYPE)
+                    for k, s in enumerate(mine):
+                        w, r = O.encode(img[rows * s:rows * (s + 1)])
+                        words[k, :len(w)] = torch.from_numpy(w.view(np.int32).copy())
+                        for f in ("n_full_words", "tail_bits", "tail_word", "total_bits_unstuffed", "total_bytes_stuffed"):
+                            recs[k][f] = getattr(r, f)
+                    return words, torch.from_numpy(recs.view(np.uint8).reshape(len(mine), 32).copy())
+
+            table, payload = pkg.distributed.encode_striped_image(Coder(), n_stripes)
+            if rank == 0:
+                np.save(os.path.join(out_dir, "table.npy"), table)
+                np.save(os.path.join(out_dir, "payload.npy"), payload.numpy().view(np.uint32))
+            else:
+                assert table is None and payload is None
+        elif mode == "mono_resident":
+            for k, img in enumerate(mono_images()):
+                lo, hi = pkg.distributed.band_rows(img.shape[0], rank, world)
+                words, res = pkg.distributed.encode_monolithic(O.OracleBandResident(img, lo, hi))
+                if rank == 0:
+                    np.save(os.path.join(out_dir, "mono%d.npy" % k), words.numpy().view(np.uint32))
+                    np.save(os.path.join(out_dir, "mono%d_res.npy" % k),
+                            np.array([res["n_full_words"], res["tail_bits"], res["tail_word"],
+                                      res["total_bits_unstuffed"], res["total_bytes_stuffed"]], dtype=np.int64))
+                else:
+                    assert words is None and res is None
         elif mode == "mono":
             # one stream from one band per rank; the band coder is the oracle stand-in
             for k, img in enumerate(mono_images()):
@@ -95,9 +129,10 @@ def test_shard_ranges_tile_the_batch():
     assert pkg.distributed.stripes_of_rank(8, 1, 2) == [1, 3, 5, 7]
 
 
-def test_stripe_gather_two_ranks(tmp_path):
+@pytest.mark.parametrize("mode", ["stripes", "stripes_resident"])
+def test_stripe_gather_two_ranks(tmp_path, mode):
     import oracle_lib as O
-    run("stripes", tmp_path)
+    run(mode, tmp_path)
     table = np.load(tmp_path / "table.npy")
     payload = np.load(tmp_path / "payload.npy")
     img = natural_like(96, 72, 5)
@@ -122,10 +157,12 @@ def test_batch_sharding_two_ranks(tmp_path):
         assert sizes[i] == len(O.encode(img)[0])
 
 
-def test_monolithic_stream_from_two_bands(tmp_path):
-    """Two ranks, one band each: the ORed words are the whole image's single stream."""
+@pytest.mark.parametrize("mode", ["mono", "mono_resident"])
+def test_monolithic_stream_from_two_bands(tmp_path, mode):
+    """Two ranks, one band each: the ORed words are the whole image's single stream.  With the figures passed as
+    integers through the host, and kept in tensors until the spans have been gathered."""
     import oracle_lib as O
-    run("mono", tmp_path)
+    run(mode, tmp_path)
     for k, img in enumerate(mono_images()):
         want, r = O.encode(img)
         got = np.load(tmp_path / ("mono%d.npy" % k))

@@ -137,13 +137,55 @@ def test_stripe_gather_and_band_merge_fed_by_the_hip_path(one_rank_group):
             assert table[s, 6] == len(want) and np.array_equal(payload[off:off + len(want)], want)
             off += len(want)
         assert off == len(payload)
+        # the same with all stripes of the rank coded by one call and their records gathered unread
+        table2, payload2 = pkg.distributed.encode_striped_image(pkg.distributed.HipStripes(e, d_img, n_stripes), n_stripes,
+                                                                device=dev)
+        assert np.array_equal(table2, table) and np.array_equal(payload2.cpu().numpy().view(np.uint32), payload)
         # one stream: the band coder is the HIP segment path, the words never leave the GPU before the merge
         lo, hi = pkg.distributed.band_rows(img.shape[0], 0, 1)
-        words, res = pkg.distributed.encode_monolithic(pkg.distributed.HipBand(e, d_img, lo, hi), device=dev)
         want, r = O.encode(img)
-        words = words.cpu().numpy().view(np.uint32)
-        assert (res["n_full_words"], res["tail_bits"], res["tail_word"]) == (r.n_full_words, r.tail_bits, r.tail_word)
-        assert np.array_equal(words[:len(want)], want) and not words[len(want):].any()
+        for coder in (pkg.distributed.HipBand, pkg.distributed.HipBandResident):
+            words, res = pkg.distributed.encode_monolithic(coder(e, d_img, lo, hi), device=dev)
+            words = words.cpu().numpy().view(np.uint32)
+            assert (res["n_full_words"], res["tail_bits"], res["tail_word"]) == (r.n_full_words, r.tail_bits, r.tail_word)
+            assert np.array_equal(words[:len(want)], want) and not words[len(want):].any()
+
+
+def test_bands_with_their_figures_left_on_the_gpu():
+    """The device-resident segment calls: several bands of one image, each on a context of its own, offsets summed
+    by torch on the GPU from the figures the calls leave there -- no copy to the host and no wait until the spans
+    are read at the end; the ORed words are the whole image's stream."""
+    pkg = load_pkg()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(3)
+    for shape, cuts in (((96, 200, 3), [0, 8, 40, 96]), ((512, 1024, 3), [0, 64, 256, 264, 512]), ((24, 8, 3), [0, 8, 16, 24])):
+        img = natural_like(shape[0], shape[1], 40 + shape[0])
+        img[shape[0] // 3:shape[0] // 2] = rng.integers(0, 256, (shape[0] // 2 - shape[0] // 3, shape[1], 3), dtype=np.uint8)
+        if shape[1] == 8:
+            img[8:] = img[8, 0]  # a last band of 18 bits inside the word the band before it ends in
+        d_img = torch.from_numpy(img).to(dev)
+        want, r = O.encode(img)
+        encs = [pkg.JpegTop(stream=torch.cuda.current_stream().cuda_stream) for _ in cuts[1:]]
+        try:
+            bands = [pkg.distributed.HipBandResident(e, d_img, a, b) for e, a, b in zip(encs, cuts[:-1], cuts[1:])]
+            rows = torch.stack([b.encode() for b in bands])
+            zero = torch.zeros(1, dtype=torch.int64, device=dev)
+            ffs = torch.cat([b.count(rows[:i, 0].sum().reshape(1), rows[i - 1, 1].reshape(1) if i else zero)
+                             for i, b in enumerate(bands)])
+            outs = [b.write(ffs[:i].sum().reshape(1), i == len(bands) - 1) for i, b in enumerate(bands)]
+            merged = torch.zeros(len(want) + 8, dtype=torch.int32, device=dev)
+            spans = torch.stack([o[0] for o in outs]).cpu().numpy()  # the first wait
+            for (span, rec, words), (fw, n) in zip(outs, spans):
+                assert n <= words.numel()
+                merged[int(fw):int(fw) + int(n)] |= words[:int(n)]
+            got = merged.cpu().numpy().view(np.uint32)
+            rec = outs[-1][1].cpu().numpy().view(pkg.RESULT_DTYPE)[0]
+            assert np.array_equal(got[:len(want)], want) and not got[len(want):].any()
+            assert (int(rec["n_full_words"]), int(rec["tail_bits"]), int(rec["total_bytes_stuffed"]), int(rec["status"])) == \
+                   (r.n_full_words, r.tail_bits, r.total_bytes_stuffed, 0)
+        finally:
+            for e in encs:
+                e.close()
 
 
 def test_two_streams_share_one_context():
