@@ -268,7 +268,7 @@ int jpegenc_set_workspace_limit(jpegenc_ctx* ctx, size_t bytes);
 int jpegenc_set_pipeline(jpegenc_ctx* ctx, int mode);
 
 /* How the encode kernel sizes the per-block staging regions in LDS.  No counterpart in jpeg_top and no
- * effect on the output: only on speed.  Small regions (1440 bits per block of Y, Cb and Cr together) let
+ * effect on the output: only on speed.  Small regions (1408 bits per block of Y, Cb and Cr together) let
  * twelve wavefronts share a compute unit and are right for photographic content up to about 2.5 bytes per
  * pixel; a group of 64 blocks that holds a longer block is coded twice.  Large regions (2272 bits, more than
  * a block of uniform noise needs on average) leave room for eight wavefronts and cost 15 % where small ones

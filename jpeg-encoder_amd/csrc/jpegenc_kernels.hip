@@ -575,15 +575,28 @@ __device__ __forceinline__ int lead_bits_half(int t2) {
 // the coder emits the table entry of (run, size 0) with no amplitude bits.  The leading-bit count gives such a value
 // size 11, which no other AC value has: the table holds those entries at size 11 (build_htab), and only the
 // amplitude has to go.  Used by the coefficient-fed variant; the variants fed from pixels never meet the value.
-template <bool GUARD, bool MERGE, bool EXACT = false>
+// TAB8: the table as eight-byte entries (code << size, length) at htab, one LDS read per lookup; else a word array at
+// htab and a byte array at hlen.
+template <bool GUARD, bool MERGE, bool EXACT = false, bool TAB8 = false>
 __device__ __forceinline__ void encode_block_pairs(const int (&tp)[32], int dc, int dc_pred, bool cb_eob_quirk,
                                                    const uint32_t* htab, const uint8_t* hlen, uint32_t* priv,
                                                    BitWriter& bw) {
+    struct Entry {
+        uint32_t h, l;
+    };
+    auto entry = [&](uint32_t at) -> Entry {
+        if constexpr (TAB8) {
+            const uint2 e = reinterpret_cast<const uint2*>(htab)[at];
+            return {e.x, e.y};
+        } else {
+            return {htab[at], hlen[at]};
+        }
+    };
     {   // DC difference, 12 bit (cr_huff.sv:1317)
         const int t = amp_src(dc - dc_pred);
         const uint32_t size = mag_bits(lead_bits(t));
-        const uint32_t at = ((uint32_t)size << 5) | kHtabDcSize;
-        bw_emit<GUARD>(bw, htab[at], amp_bits(t, size), hlen[at], priv);
+        const Entry e = entry(((uint32_t)size << 5) | kHtabDcSize);
+        bw_emit<GUARD>(bw, e.h, amp_bits(t, size), e.l, priv);
     }
     // The group-of-eight all-zero tests (cr_huff.sv:190-204) only ever ask about zig-zag positions 16..31, 32..47
     // and 48..63 together with everything behind them.  Of the registers of tp, some hold two positions of one of
@@ -625,7 +638,8 @@ __device__ __forceinline__ void encode_block_pairs(const int (&tp)[32], int dc, 
         coef_at(kc, lead, size, amp);
         const uint32_t at = or3_fast(r5, size, eob_of(k));
         r5 = and3_fast(r5 + 32u, (uint32_t)lead, run_mask);
-        return AcSym{htab[at], amp, hlen[at]};
+        const Entry e = entry(at);
+        return AcSym{e.h, amp, e.l};
     };
     using std::integral_constant;
     if constexpr (MERGE) {
@@ -691,8 +705,8 @@ __device__ __forceinline__ void encode_block_pairs(const int (&tp)[32], int dc, 
         uint32_t size, amp;
         coef_at(integral_constant<int, 63>{}, lead, size, amp);
         const uint32_t zmask = (uint32_t)(lead >> 31);
-        const uint32_t at = ((r5 | size) & ~zmask) | ((uint32_t)kHtabEob & zmask);
-        bw_emit<GUARD>(bw, htab[at], amp, hlen[at], priv);
+        const Entry e = entry(((r5 | size) & ~zmask) | ((uint32_t)kHtabEob & zmask));
+        bw_emit<GUARD>(bw, e.h, amp, e.l, priv);
     }
 }
 
@@ -1228,10 +1242,11 @@ __device__ __forceinline__ Gathered gather_states(const uint64_t* st, uint32_t c
 // LDS budget: per wave 64 regions of REGION words (one per lane, for the first pass), per workgroup one Huffman
 // table.  The first pass gives every lane one region; if any lane overflows, the chunk is redone with regions cut
 // to the lengths the first pass has counted.  Three sizes, measured on 1080p batches:
-//   small  47 words (45 usable = 1440 bits per MCU, 2.8 bytes per pixel), four waves per workgroup sharing the
-//          table: three workgroups = twelve waves per CU (three per SIMD).  Enough for photographic content.
-//          (41 words with one wave per workgroup is the same speed or 1 % slower and overflows from 2.0 bytes per
-//          pixel on; 49 words no longer fit three workgroups, 20 % slower.)
+//   small  46 words (44 usable = 1408 bits per MCU, 2.75 bytes per pixel), four waves per workgroup sharing the
+//          table (eight-byte entries): three workgroups = twelve waves per CU (three per SIMD).  Enough for
+//          photographic content.  (47 words with the table split into a word and a byte array: 2 % slower; 41 words
+//          with one wave per workgroup: 3 % slower and overflows from 2.0 bytes per pixel on; 49 words no longer fit
+//          three workgroups, 20 % slower.)
 //   large  73 words (71 usable = 2272 bits, 4.4 bytes per pixel), two waves per workgroup, four workgroups = eight
 //          waves per CU: 15 % slower where small regions suffice, up to twice as fast where they do not (uniform
 //          noise, 2150 bits per MCU on average, is done in one pass: 181 against 85 Gpixel/s with 65 words).
@@ -1241,7 +1256,14 @@ __device__ __forceinline__ Gathered gather_states(const uint64_t* st, uint32_t c
 // EncodeParams::stats).  The variants off the common path (quantising: short streams; rows not 8-byte aligned)
 // keep 41 words and one wave per workgroup, twelve per CU: with 47 words they would spill registers.  Odd region
 // strides keep lanes on different LDS banks.
-[[maybe_unused]] constexpr int kRegionBasic = 41, kRegionSmall = 47, kRegionFused = 65, kRegionLarge = 73;
+// JPEGENC_HTAB8 = words per small region when the common variant keeps its Huffman table as eight-byte entries (one
+// LDS read per lookup instead of two: encode kernel 3.20 against 3.26 ms per 768 frames), 0 = the split table with
+// 47-word regions.  46 words and the 4 KB table are what three workgroups per CU have room for (52 992 of 53 248
+// bytes); the even stride costs nothing measurable (45 words: 3.19 / 3.21 against 3.20 / 3.21 ms).
+#ifndef JPEGENC_HTAB8
+#define JPEGENC_HTAB8 46
+#endif
+[[maybe_unused]] constexpr int kRegionBasic = 41, kRegionSmall = JPEGENC_HTAB8 ? JPEGENC_HTAB8 : 47, kRegionFused = 65, kRegionLarge = 73;
 [[maybe_unused]] constexpr int kSmallWaves = 4, kLargeWaves = 2;  // per workgroup
 constexpr uint32_t kSmallRegionBits = (kRegionSmall - 2) * 32;  // what a lane may emit in a small region
 constexpr uint32_t kLargeRegionBits = (kRegionLarge - 2) * 32;
@@ -1286,7 +1308,8 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
     uint32_t* const priv = flat + woff;
     // the Huffman table: code << size as words, then code length + size as bytes (one array: the single-launch
     // form reuses it as the stage of the stuffing step)
-    __shared__ __attribute__((aligned(16))) uint32_t tables[kHtabEntries + kHtabEntries / 4];
+    constexpr bool kTab8 = (JPEGENC_HTAB8 != 0) && REGION == kRegionSmall && !QUANT && LPM == 1 && WAVES == kSmallWaves;
+    __shared__ __attribute__((aligned(16))) uint32_t tables[kTab8 ? 2 * kHtabEntries : kHtabEntries + kHtabEntries / 4];
     uint32_t* const htab = tables;
     uint8_t* const hlen = reinterpret_cast<uint8_t*>(tables + kHtabEntries);
     static_assert(!FUSED || sizeof(tables) >= kStageBytes, "the stage fits the table's place");
@@ -1327,8 +1350,12 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
         for (int j = 0; j < kHtabEntries / kThreads; ++j) e[j] = p.htab[threadIdx.x + kThreads * j];
 #pragma unroll
         for (int j = 0; j < kHtabEntries / kThreads; ++j) {
-            htab[threadIdx.x + kThreads * j] = e[j] & 0x7FFFFFFu;
-            hlen[threadIdx.x + kThreads * j] = (uint8_t)(e[j] >> 27);
+            if constexpr (kTab8) {
+                reinterpret_cast<uint2*>(tables)[threadIdx.x + kThreads * j] = make_uint2(e[j] & 0x7FFFFFFu, e[j] >> 27);
+            } else {
+                htab[threadIdx.x + kThreads * j] = e[j] & 0x7FFFFFFu;
+                hlen[threadIdx.x + kThreads * j] = (uint8_t)(e[j] >> 27);
+            }
         }
     }
     if (WAVES > 1 && c >= p.cpi) {  // a wave behind the image's last chunk: only the table's barrier is its business
@@ -1545,9 +1572,9 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
             const int pred = __builtin_amdgcn_update_dpp(h, dc, 0x138, 0xF, 0xF, false);
             if constexpr (kPairs) {
                 if (!fit)
-                    encode_block_pairs<false, kJoin, COEFFS>(tp, dc, pred, comp == 1 && cb_quirk, htab, hlen, flat, bw);
+                    encode_block_pairs<false, kJoin, COEFFS, kTab8>(tp, dc, pred, comp == 1 && cb_quirk, htab, hlen, flat, bw);
                 else
-                    encode_block_pairs<true, false, COEFFS>(tp, dc, pred, comp == 1 && cb_quirk, htab, hlen, flat, bw);
+                    encode_block_pairs<true, false, COEFFS, kTab8>(tp, dc, pred, comp == 1 && cb_quirk, htab, hlen, flat, bw);
             } else {
                 if (!fit)
                     encode_block<false, QUANT, kJoin>(x, pred, comp == 1 && cb_quirk, htab, hlen, flat, bw);
