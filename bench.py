@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument("--ws-mb", type=int, default=0, help="workspace limit in MiB (0: library default)")
     ap.add_argument("--regions", choices=["auto", "small", "large"], default="auto",
                     help="LDS staging regions of the encode kernel (jpegenc_set_region_mode)")
+    ap.add_argument("--slots", choices=["adaptive", "worst"], default="adaptive",
+                    help="scratch per chunk: sized from the chunk lengths of earlier calls, or the worst case (jpegenc_set_slot_mode)")
     ap.add_argument("--split", action="store_true", help="separate kernels also for small calls (jpegenc_set_pipeline)")
     ap.add_argument("--sync-each-step", action="store_true",
                     help="wait for every step before the next is queued: the latency of one call, not the rate of a queue of them")
@@ -174,7 +176,12 @@ def main():
     enc.set_region_mode({"auto": enc.REGIONS_AUTO, "small": enc.REGIONS_SMALL, "large": enc.REGIONS_LARGE}[args.regions])
     if args.split:
         enc.set_pipeline(enc.PIPELINE_SPLIT)
-    enc.reserve(nf, w, h)  # the steps below only enqueue work
+    if args.slots == "adaptive":
+        # the first call sizes the chunk slots from a first few frames (and waits for them, once); the warm-up
+        # below brings the workspace to its final size, so the timed steps only enqueue work
+        enc.set_slot_mode(enc.SLOTS_ADAPTIVE)
+    else:
+        enc.reserve(nf, w, h)  # the steps below only enqueue work
 
     def step():
         enc.encode_batch_device(frames.data_ptr(), nf, w, h, w * 3, h * w * 3, words.data_ptr(), cap_words,
@@ -187,8 +194,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1 if args.slots == "adaptive" else 0)):
         step()
+        if args.slots == "adaptive":
+            enc.synchronize()  # (statistics of this call in before the next one sizes its slots)
     barrier()
     enc.kernel_times(reset=True)
     enc.set_profiling(not args.no_profile)
@@ -233,6 +242,8 @@ def main():
         "config": {"workload": workload, "frames_per_gpu": nf, "total_frames": total_frames, "width": w, "height": h,
                    "sharding": "independent images, no collective"},
         "all_images_ok": ok, "out_bytes_per_pixel": round(out_bytes_per_px, 4),
+        "workspace": {"slots": args.slots, "bytes": enc.workspace_bytes(),
+                      "bytes_per_frame": round(enc.workspace_bytes() / float(nf))},
     }
     over_small, over_large, counted = enc.region_stats()
     if counted:  # chunks of the last counted launch that hold an MCU too long for a small / large LDS region

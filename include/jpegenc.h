@@ -33,6 +33,7 @@ extern "C" {
 #define JPEGENC_E_NOMEM (-5)
 #define JPEGENC_E_STATE (-6) /* calls out of order: push/end_of_file protocol, segment calls */
 #define JPEGENC_E_LIMIT (-7) /* jpegenc_encode_batch_noalloc: the call exceeds JPEGENC_NOALLOC_MAX_CHUNKS */
+#define JPEGENC_E_AGAIN (-8) /* per-image status under JPEGENC_SLOTS_ADAPTIVE: repeat the call (see jpegenc_set_slot_mode) */
 
 /* flags for the encode calls */
 #define JPEGENC_HOST_PTRS 0u   /* rgb / words_out / results are host memory (copied, call blocks) */
@@ -252,6 +253,25 @@ const char* jpegenc_kernel_name(int index);
  * whose input and output copies fit the budget.  When the device cannot provide the budget the
  * sub-batches are halved until they fit; JPEGENC_E_NOMEM when not even one image does. */
 int jpegenc_set_workspace_limit(jpegenc_ctx* ctx, size_t bytes);
+
+/* How much scratch a group of 64 blocks gets for its intermediate stream.  No counterpart in jpeg_top.
+ * WORST_CASE (default): 39 936 bytes, what 64 blocks can need at most -- no call can ever outgrow it; 20.2 MB per
+ * 1080p frame, of which photographic content touches about a tenth.
+ * ADAPTIVE: as much as the longest group seen in the context's earlier large calls (more than 2048 groups) and a
+ * quarter more, between 4 KB and the worst case: 1024 frames of 1080p photographs then take 3 to 4 GB instead of
+ * 20.7.  The context's first large call sends a first few images through with worst-case scratch and waits, once,
+ * for their statistics before it sizes the rest (so that call synchronises the stream once, even with device
+ * pointers).  The price: when content turns up whose groups are longer than anything before by more than that
+ * quarter, the groups that do not fit are not coded, and their images get status JPEGENC_E_AGAIN (nothing valid
+ * in their words).  Host-pointer calls repeat such a call themselves (the second go cannot fail); a device-pointer
+ * caller checks results[i].status as for JPEGENC_E_TOO_SMALL and repeats the call -- the statistics of the failed
+ * call have told the context the size it needs by the time its results can be read.  The scratch never shrinks;
+ * its size follows the longest group down by an eighth after four large calls in a row that stay below it. */
+#define JPEGENC_SLOTS_WORST_CASE 0
+#define JPEGENC_SLOTS_ADAPTIVE 1
+int jpegenc_set_slot_mode(jpegenc_ctx* ctx, int mode);
+/* Bytes of device memory the context's workspace holds at the moment. */
+size_t jpegenc_workspace_bytes(const jpegenc_ctx* ctx);
 
 /* Launch structure.  No counterpart in jpeg_top and no effect on the output.  AUTO (default): a call of at
  * most 2048 groups of 64 blocks (four 1080p frames) with all-ones tables and 8-byte-aligned rows runs as ONE

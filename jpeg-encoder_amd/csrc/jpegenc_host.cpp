@@ -122,8 +122,18 @@ struct jpegenc_ctx {
     int region_mode = JPEGENC_REGIONS_AUTO;
     bool large_regions = false;
     int small_votes = 0;  // launches in a row whose counts favoured small regions while large ones were in use
-    DevBuf<uint32_t> stats;
+    DevBuf<uint32_t> stats;  // [kEncodeStatsWords] + one flag word per image of a launch group (img_flags)
     uint32_t* stats_host = nullptr;
+
+    // Stride of the chunk slots (jpegenc_set_slot_mode).  ADAPTIVE: `est_bits` follows the longest chunk of the
+    // launches whose statistics have arrived -- chunks longer than 7/8 of it report their length, so it is exact
+    // while chunks reach that band, and it shrinks by an eighth per launch while none does -- and the slots get
+    // that length and a quarter more.
+    int slot_mode = JPEGENC_SLOTS_WORST_CASE;
+    uint32_t est_bits = 0;      // 0: nothing seen yet (worst-case slots, and every chunk reports)
+    int quiet_launches = 0;     // statistics blocks in a row in which no chunk reported
+    uint64_t stats_seen = 0;    // sequence number of the last statistics block taken into est_bits
+    uint64_t stats_issued = 0;  // launches that collect statistics, so far
 
     // Single-launch form of small launches (jpegenc_set_pipeline): hand-off words of the chunks, 3 per chunk
     int pipeline = JPEGENC_PIPELINE_AUTO;
@@ -252,16 +262,55 @@ constexpr uint32_t kInlineScanMaxCpi = 8192;
 // Geometry of a call and the number of images one launch group holds under the workspace budget.
 struct Plan {
     uint32_t mcu_w, n_mcu, cpi;
-    uint32_t sub;  // images per launch group
+    uint32_t sub;         // images per launch group
+    uint32_t slot_words;  // stride of the chunk slots
 };
 
-int make_plan(const jpegenc_ctx* ctx, int n_images, int w, int h, Plan* pl) {
+// Takes the statistics that have arrived since the last look into the estimate of the longest chunk (see
+// jpegenc_ctx::est_bits).  The words are written by asynchronous copies behind earlier launches; any mix of old and
+// new words only makes the estimate a little stale.
+void update_slot_estimate(jpegenc_ctx* ctx) {
+    const volatile uint32_t* h = ctx->stats_host;
+    const uint32_t seq = h[16 * 16 + 3];
+    if (seq == 0 || seq == uint32_t(ctx->stats_seen)) return;
+    ctx->stats_seen = seq;
+    uint32_t longest = 0, unstored = 0;
+    for (int i = 0; i < 16; ++i) {
+        longest = std::max<uint32_t>(longest, uint32_t(h[16 * i + 2]));
+        unstored += h[16 * i + 3];
+    }
+    const uint32_t report = h[16 * 16 + 1];
+    const uint32_t worst = uint32_t(kSlotWords) * 32u;
+    if (longest > worst) return;  // (not a length: torn or foreign words)
+    if (longest) {
+        // exact: every chunk above `report` took part in the maximum (an unstored chunk is above it by far)
+        ctx->est_bits = unstored ? std::max(ctx->est_bits, longest) : longest;
+        ctx->quiet_launches = 0;
+    } else if (report != 0xFFFFFFFFu && report < ctx->est_bits && ++ctx->quiet_launches >= 4) {
+        ctx->est_bits = std::max<uint32_t>(report, 1);  // four launches with nothing above `report`: down an eighth
+        ctx->quiet_launches = 0;
+    }
+}
+
+uint32_t current_slot_words(jpegenc_ctx* ctx, bool adaptive_allowed) {
+    if (!adaptive_allowed || ctx->slot_mode != JPEGENC_SLOTS_ADAPTIVE) return uint32_t(kSlotWords);
+    update_slot_estimate(ctx);
+    if (ctx->est_bits == 0) return uint32_t(kSlotWords);
+    uint64_t words = (uint64_t(ctx->est_bits) * 5 / 4 + 31) / 32 + 64;
+    words = (words + 255) & ~uint64_t(255);
+    return uint32_t(std::min<uint64_t>(std::max<uint64_t>(words, kMinSlotWords), uint64_t(kSlotWords)));
+}
+
+int make_plan(jpegenc_ctx* ctx, int n_images, int w, int h, Plan* pl, bool adaptive_allowed = true) {
     pl->mcu_w = uint32_t(w / 8);
     const uint64_t n_mcu64 = uint64_t(pl->mcu_w) * uint32_t(h / 8);
     if (n_mcu64 == 0 || n_mcu64 > 0x7FFFFFFFull) return JPEGENC_E_UNSUPPORTED;
     pl->n_mcu = uint32_t(n_mcu64);
     pl->cpi = (pl->n_mcu + kChunkMcus - 1) / kChunkMcus;
-    const uint64_t per_image = uint64_t(pl->cpi) * kSlotWords * 4;
+    // (small calls keep worst-case slots: nothing to save, and their kernels collect no statistics)
+    pl->slot_words = uint64_t(n_images) * pl->cpi > kSingleLaunchMaxChunks ? current_slot_words(ctx, adaptive_allowed)
+                                                                           : uint32_t(kSlotWords);
+    const uint64_t per_image = uint64_t(pl->cpi) * pl->slot_words * 4;
     uint64_t sub = ctx->ws_limit / per_image;
     if (sub < 1) sub = 1;
     if (sub > uint64_t(n_images)) sub = uint64_t(n_images);
@@ -270,8 +319,9 @@ int make_plan(const jpegenc_ctx* ctx, int n_images, int w, int h, Plan* pl) {
     return JPEGENC_OK;
 }
 
-hipError_t reserve_workspace(jpegenc_ctx* ctx, size_t chunks) {
-    hipError_t e = ctx->slots.reserve((chunks + 1) * size_t(kSlotWords));
+hipError_t reserve_workspace(jpegenc_ctx* ctx, size_t chunks, uint32_t slot_words = uint32_t(kSlotWords)) {
+    // behind the last slot: what the stuffing kernels may read past a chunk's end (five 1 KB steps and a word)
+    hipError_t e = ctx->slots.reserve(chunks * size_t(slot_words) + std::max<size_t>(slot_words, 2048));
     if (e == hipSuccess) e = ctx->chunk_bits.reserve(chunks);
     if (e == hipSuccess) e = ctx->chunk_ff.reserve(chunks);
     if (e == hipSuccess) e = ctx->bit_off.reserve(chunks);
@@ -283,7 +333,9 @@ hipError_t reserve_workspace(jpegenc_ctx* ctx, size_t chunks) {
 // the memory) the launch groups are halved until they fit, down to one image.
 int reserve_for_plan(jpegenc_ctx* ctx, Plan* pl) {
     for (;;) {
-        const hipError_t e = reserve_workspace(ctx, size_t(pl->sub) * pl->cpi);
+        hipError_t e = reserve_workspace(ctx, size_t(pl->sub) * pl->cpi, pl->slot_words);
+        if (e == hipSuccess && pl->slot_words != uint32_t(kSlotWords))
+            e = ctx->stats.reserve(size_t(kEncodeStatsWords) + pl->sub);  // + the images' flag words
         if (e == hipSuccess) return JPEGENC_OK;
         if (e != hipErrorOutOfMemory) return fail_hip(ctx, e, "workspace allocation");
         (void)hipGetLastError();  // the failed allocation is not left behind as a pending error
@@ -304,6 +356,12 @@ Workspace ctx_workspace(const jpegenc_ctx* ctx) {
     ws.ff_off = ctx->ff_off.p;
     return ws;
 }
+Workspace ctx_workspace(const jpegenc_ctx* ctx, const Plan& pl) {
+    Workspace ws = ctx_workspace(ctx);
+    ws.slot_words = pl.slot_words;
+    ws.img_flags = pl.slot_words != uint32_t(kSlotWords) ? ctx->stats.p + kEncodeStatsWords : nullptr;
+    return ws;
+}
 
 // Marks the workspace as in use by what has just been enqueued on the context's stream.
 int workspace_used(jpegenc_ctx* ctx) {
@@ -312,19 +370,24 @@ int workspace_used(jpegenc_ctx* ctx) {
     return JPEGENC_OK;
 }
 
-// Region size for the next launch of the encode kernel, and its statistics buffer (zeroed on the stream).  Only
-// the common kernel variant (8-byte-aligned rows, all-ones tables) exists with large regions.
-int choose_regions(jpegenc_ctx* ctx, EncodeParams* ep, int align, uint64_t chunks) {
+// Region size for the next launch of the encode kernel, and its statistics buffer (zeroed on the stream, together
+// with the images' flag words when the slots are not the worst case).  Only the common kernel variant (8-byte-aligned
+// rows, all-ones tables) exists with large regions.
+int choose_regions(jpegenc_ctx* ctx, EncodeParams* ep, int align, uint64_t chunks, uint32_t n_images) {
     ep->stats = nullptr;
     ep->large_regions = 0;
-    if (ctx->quant || align < 8) return JPEGENC_OK;
-    if (chunks <= kSingleLaunchMaxChunks && ctx->region_mode == JPEGENC_REGIONS_AUTO) {
+    ep->report_bits = 0xFFFFFFFFu;
+    ep->stats_seq = 0;
+    const bool common = !ctx->quant && align >= 8;
+    const bool adaptive = ctx->slot_mode == JPEGENC_SLOTS_ADAPTIVE && chunks > kSingleLaunchMaxChunks;
+    if (!common && !adaptive) return JPEGENC_OK;
+    if (common && chunks <= kSingleLaunchMaxChunks && ctx->region_mode == JPEGENC_REGIONS_AUTO) {
         // every chunk is resident at once even with large regions: they cost nothing here, and a small call is
         // spared the two stream operations of the statistics
         ep->large_regions = 1;
         return JPEGENC_OK;
     }
-    if (ctx->region_mode == JPEGENC_REGIONS_AUTO) {
+    if (common && ctx->region_mode == JPEGENC_REGIONS_AUTO) {
         // whatever the last completed copy left in the pinned words: a heuristic, any value is safe
         const volatile uint32_t* h = ctx->stats_host;
         uint64_t over_small = 0, over_large = 0;
@@ -353,12 +416,17 @@ int choose_regions(jpegenc_ctx* ctx, EncodeParams* ep, int align, uint64_t chunk
                 ctx->small_votes = 0;
             }
         }
-    } else {
+    } else if (common) {
         ctx->large_regions = ctx->region_mode == JPEGENC_REGIONS_LARGE;
     }
-    ep->large_regions = ctx->large_regions ? 1u : 0u;
+    ep->large_regions = (common && ctx->large_regions) ? 1u : 0u;
     ep->stats = ctx->stats.p;
-    HIPCHK(ctx, hipMemsetAsync(ctx->stats.p, 0, kEncodeStatsWords * 4, ctx->stream));
+    if (++ctx->stats_issued == 0 || uint32_t(ctx->stats_issued) == 0) ctx->stats_issued = 1;
+    ep->stats_seq = uint32_t(ctx->stats_issued);
+    // chunks in the top eighth below the longest seen so far report their length (see jpegenc_ctx::est_bits)
+    if (adaptive) ep->report_bits = ctx->est_bits - ctx->est_bits / 8;
+    const size_t words = size_t(kEncodeStatsWords) + (ep->img_flags ? n_images : 0);
+    HIPCHK(ctx, hipMemsetAsync(ctx->stats.p, 0, words * 4, ctx->stream));
     return JPEGENC_OK;
 }
 
@@ -403,6 +471,10 @@ int run_group(jpegenc_ctx* ctx, const Workspace& ws, bool timed, const Plan& pl,
     ep.flags = ctx->flags;
     ep.coeffs = coeffs;
     ep.slots = ws.slots;
+    ep.slot_words = ws.slot_words;
+    ep.report_bits = 0xFFFFFFFFu;
+    ep.stats_seq = 0;
+    ep.img_flags = ws.img_flags;
     ep.chunk_bits = ws.chunk_bits;
     ep.htab = ctx->htab.p;
     ep.qmul = (ctx->quant && !coeffs) ? ctx->qmul.p : nullptr;
@@ -451,9 +523,11 @@ int run_group(jpegenc_ctx* ctx, const Workspace& ws, bool timed, const Plan& pl,
                                    ? 1u
                                    : 0u;
     } else {
-        rc_regions = choose_regions(ctx, &ep, align, uint64_t(n) * cpi);
+        rc_regions = choose_regions(ctx, &ep, align, uint64_t(n) * cpi, n);
     }
     if (rc_regions != JPEGENC_OK) return rc_regions;
+    if (ep.img_flags && !ep.stats)  // (the flag words are zeroed with the statistics; without those, on their own)
+        HIPCHK(ctx, hipMemsetAsync(ep.img_flags, 0, size_t(n) * 4, ctx->stream));
     {
         ProfScope ps(ctx, K_ENCODE);
         HIPCHK(ctx, launch_encode(ep, n, align, ctx->stream));
@@ -485,6 +559,8 @@ int run_group(jpegenc_ctx* ctx, const Workspace& ws, bool timed, const Plan& pl,
     }
     StuffParams tp;
     tp.slots = ws.slots;
+    tp.slot_words = ws.slot_words;
+    tp.img_flags = ws.img_flags;
     tp.chunk_bits = ws.chunk_bits;
     tp.bit_off = ws.bit_off;
     tp.chunk_ff = ws.chunk_ff;
@@ -529,13 +605,32 @@ int encode_device(jpegenc_ctx* ctx, const uint8_t* rgb, int n_images, int w, int
     int rc = make_plan(ctx, n_images, w, h, &pl);
     if (rc != JPEGENC_OK) return rc;
     ctx->seg_ready = ctx->seg_counted = false;  // whatever a segment call left in the workspace is gone
+    const int align = pointer_align(rgb, stride, image_stride, n_images, h);
+    int done = 0;
+    if (ctx->slot_mode == JPEGENC_SLOTS_ADAPTIVE && ctx->est_bits == 0 && uint64_t(n_images) * pl.cpi > kSingleLaunchMaxChunks) {
+        // The context's first large call with slots sized from experience, and there is none yet: a first group of
+        // a few images goes through with worst-case slots, every chunk reporting its length, and the host waits
+        // for that group's statistics -- once per context -- before it sizes the slots for the rest.
+        Plan probe = pl;
+        probe.slot_words = uint32_t(kSlotWords);
+        probe.sub = uint32_t(std::min<uint64_t>(uint64_t(n_images), 2 * kSingleLaunchMaxChunks / pl.cpi + 1));  // > 2048 chunks: statistics are collected
+        rc = reserve_for_plan(ctx, &probe);
+        if (rc != JPEGENC_OK) return rc;
+        rc = run_group(ctx, ctx_workspace(ctx, probe), true, probe, rgb, probe.sub, stride, image_stride, align, words,
+                       cap_words, results);
+        if (rc != JPEGENC_OK) return rc;
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        done = int(probe.sub);
+        if (done == n_images) return workspace_used(ctx);
+        rc = make_plan(ctx, n_images - done, w, h, &pl);
+        if (rc != JPEGENC_OK) return rc;
+    }
     rc = reserve_for_plan(ctx, &pl);
     if (rc != JPEGENC_OK) return rc;
     // (The single-launch form with a lane per component block cuts an image into three times the chunks, and
     // needs no slots for them: such a chunk always fits its LDS regions -- a static_assert in the kernel.)
-    const Workspace ws = ctx_workspace(ctx);
-    const int align = pointer_align(rgb, stride, image_stride, n_images, h);
-    for (int first = 0; first < n_images; first += int(pl.sub)) {
+    const Workspace ws = ctx_workspace(ctx, pl);
+    for (int first = done; first < n_images; first += int(pl.sub)) {
         const uint32_t n = uint32_t(std::min<int64_t>(pl.sub, n_images - first));
         rc = run_group(ctx, ws, true, pl, rgb + int64_t(first) * image_stride, n, stride, image_stride, align,
                        words + uint64_t(first) * cap_words, cap_words, results + first);
@@ -594,12 +689,21 @@ int encode_staged(jpegenc_ctx* ctx, const uint8_t* d_rgb, int n_images, int w, i
     const size_t img_bytes = row * size_t(h);
     MEMCHK(ctx, ctx->out_stage.reserve(cap_words * size_t(n_images)));
     MEMCHK(ctx, ctx->res_stage.reserve(size_t(n_images)));
-    int rc = encode_device(ctx, d_rgb, n_images, w, h, ptrdiff_t(row), ptrdiff_t(img_bytes), ctx->out_stage.p, cap_words,
+    int rc = JPEGENC_OK;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        rc = encode_device(ctx, d_rgb, n_images, w, h, ptrdiff_t(row), ptrdiff_t(img_bytes), ctx->out_stage.p, cap_words,
                            ctx->res_stage.p);
-    if (rc != JPEGENC_OK) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(results, ctx->res_stage.p, sizeof(jpegenc_result) * size_t(n_images),
-                               hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (rc != JPEGENC_OK) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(results, ctx->res_stage.p, sizeof(jpegenc_result) * size_t(n_images),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        bool again = false;
+        for (int i = 0; i < n_images; ++i) again = again || results[i].status == JPEGENC_E_AGAIN;
+        if (!again) break;
+        // a chunk outgrew the slots sized from earlier calls: the statistics of this call are in by now (the stream
+        // has drained) and hold its longest chunk, so the second go fits
+        update_slot_estimate(ctx);
+    }
     for (int i = 0; i < n_images; ++i) {
         uint64_t nw = results[i].n_full_words + (results[i].tail_bits ? 1 : 0);
         if (nw > cap_words) {
@@ -834,7 +938,7 @@ int jpegenc_encode_batch_noalloc(jpegenc_ctx* ctx, const uint8_t* rgb, int n_ima
     if (n_images > 1 && (image_stride < 0 ? -image_stride : image_stride) < stride * ptrdiff_t(h) && image_stride != 0)
         return JPEGENC_E_BAD_ARG;
     Plan pl;
-    rc = make_plan(ctx, n_images, w, h, &pl);
+    rc = make_plan(ctx, n_images, w, h, &pl, false);  // the static workspace has worst-case slots
     if (rc != JPEGENC_OK) return rc;
     if (uint64_t(n_images) * pl.cpi > kStaticChunks) {
         char buf[160];
@@ -916,12 +1020,12 @@ int jpegenc_encode_coeffs(jpegenc_ctx* ctx, const int16_t* coeffs, int w, int h,
     DevGuard guard(ctx->device);
     HIPCHK(ctx, guard.err);
     Plan pl;
-    int rc = make_plan(ctx, 1, w, h, &pl);
+    int rc = make_plan(ctx, 1, w, h, &pl, false);  // (a checking aid: worst-case slots, no repeat to think of)
     if (rc != JPEGENC_OK) return rc;
     ctx->seg_ready = ctx->seg_counted = false;
     rc = reserve_for_plan(ctx, &pl);
     if (rc != JPEGENC_OK) return rc;
-    const Workspace ws = ctx_workspace(ctx);
+    const Workspace ws = ctx_workspace(ctx, pl);
     if (flags & JPEGENC_DEVICE_PTRS) {
         if (reinterpret_cast<uintptr_t>(coeffs) & 15u) return JPEGENC_E_BAD_ARG;
         rc = run_group(ctx, ws, true, pl, nullptr, 1, 0, 0, 8, words_out, cap_words, result, coeffs);
@@ -1024,6 +1128,10 @@ int jpegenc_segment_encode_dev(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int 
     ep.flags = ctx->flags | (continues ? 4u : 0u);
     ep.coeffs = nullptr;
     ep.slots = ctx->slots.p;
+    ep.slot_words = uint32_t(kSlotWords);
+    ep.report_bits = 0xFFFFFFFFu;
+    ep.stats_seq = 0;
+    ep.img_flags = nullptr;
     ep.chunk_bits = ctx->chunk_bits.p;
     ep.htab = ctx->htab.p;
     ep.qmul = ctx->quant ? ctx->qmul.p : nullptr;
@@ -1035,7 +1143,7 @@ int jpegenc_segment_encode_dev(jpegenc_ctx* ctx, const uint8_t* rgb, int w, int 
     ep.out_stride = ep.cap_words = 0;
     ep.results = nullptr;
     const int seg_align = pointer_align(d_rgb, d_stride, 0, 1, rows);
-    int rc_regions = choose_regions(ctx, &ep, seg_align, cpi);
+    int rc_regions = choose_regions(ctx, &ep, seg_align, cpi, 1);
     if (rc_regions != JPEGENC_OK) return rc_regions;
     HIPCHK(ctx, launch_encode(ep, 1, seg_align, ctx->stream));
     rc_regions = collect_stats(ctx, ep);
@@ -1073,6 +1181,8 @@ namespace {
 StuffParams segment_params(jpegenc_ctx* ctx) {
     StuffParams tp;
     tp.slots = ctx->slots.p;
+    tp.slot_words = uint32_t(kSlotWords);
+    tp.img_flags = nullptr;
     tp.chunk_bits = ctx->chunk_bits.p;
     tp.bit_off = ctx->bit_off.p;
     tp.chunk_ff = ctx->chunk_ff.p;
@@ -1325,6 +1435,17 @@ int jpegenc_set_region_mode(jpegenc_ctx* ctx, int mode) {
     return JPEGENC_OK;
 }
 
+int jpegenc_set_slot_mode(jpegenc_ctx* ctx, int mode) {
+    if (!ctx || (mode != JPEGENC_SLOTS_WORST_CASE && mode != JPEGENC_SLOTS_ADAPTIVE)) return JPEGENC_E_BAD_ARG;
+    ctx->slot_mode = mode;
+    return JPEGENC_OK;
+}
+
+size_t jpegenc_workspace_bytes(const jpegenc_ctx* ctx) {
+    if (!ctx) return 0;
+    return ctx->slots.n * 4 + ctx->chunk_bits.n * 4 + ctx->chunk_ff.n * 4 + ctx->bit_off.n * 8 + ctx->ff_off.n * 8;
+}
+
 int jpegenc_set_workspace_limit(jpegenc_ctx* ctx, size_t bytes) {
     if (!ctx || bytes == 0) return JPEGENC_E_BAD_ARG;
     ctx->ws_limit = bytes;
@@ -1341,6 +1462,7 @@ const char* jpegenc_strerror(int code) {
         case JPEGENC_E_NOMEM: return "out of memory";
         case JPEGENC_E_STATE: return "calls out of order (port protocol or segment calls)";
         case JPEGENC_E_LIMIT: return "call exceeds the static workspace of jpegenc_encode_batch_noalloc";
+        case JPEGENC_E_AGAIN: return "a group of blocks outgrew its workspace slot (JPEGENC_SLOTS_ADAPTIVE): repeat the call";
         default: return "unknown error";
     }
 }

@@ -13,16 +13,25 @@ constexpr int kChunkMcus = 64;
 // Worst case bits per MCU: 3 component blocks x (22 DC + 63 x 26 AC) = 4980 bits = 156 words (rounded up).
 constexpr int kMaxMcuBits = 4980;
 constexpr int kMaxMcuWords = 156;
-// Chunk stream slot in the workspace, in 32-bit words: worst case of 64 MCUs.
+// Chunk stream slot in the workspace, in 32-bit words: worst case of 64 MCUs.  The stride between slots is a
+// launch parameter (slot_words): this worst case, or less when the context sizes the slots from the chunk lengths
+// it has seen (jpegenc_set_slot_mode); a chunk that does not fit a smaller slot is not stored and its image's
+// status says so.
 constexpr int kSlotWords = kChunkMcus * kMaxMcuWords;  // 9984 words = 39,936 B
+constexpr uint32_t kMinSlotWords = 1024;               // smallest stride: the stand-in count below fits it
+// What an unstored chunk reports as its length: any length from 1152 bits (what a chunk with a successor has at
+// least) that fits the smallest slot keeps the stuffing kernels' reads and writes in bounds.
+constexpr uint32_t kUnstoredChunkBits = 2048;
 
 // The workspace of one launch group, sized for `chunks` chunks.
 struct Workspace {
-    uint32_t* slots;       // [chunks + 1][kSlotWords]: the stuffing kernels read up to 1 KB past a chunk's stream
+    uint32_t* slots;       // [chunks + 1][slot_words]: the stuffing kernels read up to 1 KB past a chunk's stream
     uint32_t* chunk_bits;  // [chunks]
     uint32_t* chunk_ff;    // [chunks]
     uint64_t* bit_off;     // [chunks]
     uint64_t* ff_off;      // [chunks]
+    uint32_t slot_words = kSlotWords;  // stride between slots
+    uint32_t* img_flags = nullptr;     // [images] or nullptr: non-zero = a chunk of the image was not stored
 };
 
 // Static workspace of jpegenc_encode_batch_noalloc: room for JPEGENC_NOALLOC_MAX_CHUNKS chunks, laid out as
@@ -63,14 +72,22 @@ struct EncodeParams {
                            // stream: the DC predictors of their first MCU come from the block row above
     const int16_t* coeffs;  // nullptr, or (coefficient-fed checking variant, rgb unused) [n_images][n_mcu][3][64]:
                             // the values at the coders' inputs in their reading order, 16-byte aligned
-    uint32_t* slots;       // [n_images * cpi][kSlotWords]
+    uint32_t* slots;       // [n_images * cpi][slot_words]
+    uint32_t slot_words;   // stride between slots, kMinSlotWords .. kSlotWords
+    uint32_t report_bits;  // chunks longer than this report their length (stats word 2 of their line: maximum)
+    uint32_t stats_seq;    // copied to stats word 259: which launch the block belongs to
+    uint32_t* img_flags;   // [n_images] zeroed by the host, or nullptr (then slot_words is the worst case): set
+                           // non-zero when a chunk of the image exceeds its slot and is left unstored
     uint32_t* chunk_bits;  // [n_images * cpi]
     const uint32_t* htab;  // [kHtabEntries]
     const int32_t* qmul;   // [3][64] multipliers 4096/Q in Huffman-input order, or nullptr
     uint32_t* stats;       // [kEncodeStatsWords] or nullptr: per launch, zeroed by the host before it; words
                            // 0, 16, ..., 240 count the chunks that hold an MCU too long for a small LDS region,
-                           // words 1, 17, ..., 241 those with one too long even for a large region, word 256
-                           // receives the launch's chunk count
+                           // words 1, 17, ..., 241 those with one too long even for a large region, words 2, 18,
+                           // ... the longest chunk among those above report_bits (0: none), words 3, 19, ... the
+                           // chunks left unstored; word 256 receives the launch's chunk count, word 257 its
+                           // report_bits, word 258 its slot_words, word 259
+                           // its stats_seq
     uint32_t large_regions;  // 1: the kernel variant with large LDS regions (8 workgroups per CU instead of 12)
     // Single-launch form (small launches only, `state` != nullptr): every chunk's wave goes on to find its place
     // in the image's stream from the hand-off words of the chunks before it, stuffs its stream and writes the
@@ -101,6 +118,8 @@ struct ScanParams {
 
 struct StuffParams {
     const uint32_t* slots;
+    uint32_t slot_words;        // stride between slots
+    const uint32_t* img_flags;  // as in EncodeParams (first image of this launch), or nullptr
     const uint32_t* chunk_bits;
     uint64_t* bit_off;        // exclusive prefix of chunk_bits per image (written by the count pass when inline_scan)
     uint32_t* chunk_ff;       // count pass: number of 0xFF bytes owned by the chunk

@@ -1135,7 +1135,7 @@ __device__ __forceinline__ void write_chunk(const StuffParams& p, const uint32_t
                     w32 = (prev_tail32 >> sbits) << 8;
                 } else {
                     const uint32_t np = p.chunk_bits[gid - 1] & kCountMask;
-                    const uint32_t* Sp = S - kSlotWords;
+                    const uint32_t* Sp = S - p.slot_words;
                     const uint32_t l = np - sbits - 24u, wi = l >> 5, sh = l & 31u;
                     w32 = sh ? __builtin_amdgcn_alignbit(Sp[wi], Sp[wi + 1], 32u - sh) : Sp[wi];
                 }
@@ -1177,6 +1177,8 @@ __device__ __forceinline__ void write_chunk(const StuffParams& p, const uint32_t
             r.tail_word = r.tail_bits ? __builtin_bswap32(tail_raw) : 0u;
             const uint64_t need = r.n_full_words + (r.tail_bits ? 1 : 0) - p.out_word_base;
             r.status = (need > p.cap_words) ? (int16_t)JPEGENC_E_TOO_SMALL : (int16_t)JPEGENC_OK;
+            // a chunk of the image did not fit its workspace slot (slots sized from earlier calls): nothing here is valid
+            if (p.img_flags && p.img_flags[img]) r.status = (int16_t)JPEGENC_E_AGAIN;
             p.results[img] = r;
         }
     }
@@ -1421,11 +1423,12 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
     }
     __syncthreads();  // htab visible
 
-    uint32_t* slot = p.slots + (uint64_t)gid * kSlotWords;
+    uint32_t* slot = p.slots + (uint64_t)gid * p.slot_words;
     uint32_t chunk_total = 0;  // bits written to the slot so far
     uint32_t carry = 0;        // partial last word of the slot (left-aligned), when chunk_total % 32 != 0
     uint32_t tail8 = 0;        // last 8 bits of the stream so far (uniform)
     uint32_t tail32 = 0;       // FUSED: its last 32 bits
+    bool unstored = false;     // the chunk does not fit its slot
 
     // Pass loop.  The first pass codes all 64 lanes at once, every lane into its own region (see kRegionWords).
     // It counts every lane's bits even when a lane cannot store them, so if any lane overflowed its region
@@ -1598,7 +1601,12 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
                 if (__any((int)(Lall > kLargeRegionBits)) && lane == 0)  // ... and even for a large one
                     __hip_atomic_fetch_add(&p.stats[(gid & 15u) * 16u + 1u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (gid == 0 && lane == 0) p.stats[16 * 16] = p.n_images * p.cpi;
+            if (gid == 0 && lane == 0) {
+                p.stats[16 * 16] = p.n_images * p.cpi;
+                p.stats[16 * 16 + 1] = p.report_bits;
+                p.stats[16 * 16 + 2] = p.slot_words;
+                p.stats[16 * 16 + 3] = p.stats_seq;
+            }
         }
         if (!fit && __any((int)(Lall > cap * 32u))) {
             // words per lane: the unread word 0, the string, the zero word behind it
@@ -1690,7 +1698,12 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
         }
 
         // ---- append the stream of this pass to the slot at bit offset chunk_total -----------------
-        if (gtotal != 0) {
+        // (a chunk that outgrows its slot -- a stride below the worst case, chosen by the host from earlier launches --
+        // stores nothing from here on and only goes on counting)
+        if (chunk_total + gtotal > p.slot_words * 32u) unstored = true;  // uniform
+        if (unstored) {
+            chunk_total += gtotal;
+        } else if (gtotal != 0) {
             const uint32_t s = chunk_total & 31u, d0 = chunk_total >> 5;
             const uint32_t nw = (gtotal + 31u) >> 5;
             const uint32_t nd = (s + gtotal + 31u) >> 5;
@@ -1749,7 +1762,15 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
         }
     }
     // bit count (at most 64 * 4980 < 2^24) and, for the successor's first byte, the stream's last 8 bits
-    if (!FUSED && lane == 0) p.chunk_bits[gid] = chunk_total | (tail8 << 24);
+    if (!FUSED && lane == 0) {
+        p.chunk_bits[gid] = unstored ? kUnstoredChunkBits : (chunk_total | (tail8 << 24));
+        if (p.stats && chunk_total > p.report_bits)  // (few chunks: the host keeps report_bits just below the longest)
+            __hip_atomic_fetch_max(&p.stats[(gid & 15u) * 16u + 2u], chunk_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (unstored) {
+            if (p.img_flags) __hip_atomic_store(&p.img_flags[img], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (p.stats) __hip_atomic_fetch_add(&p.stats[(gid & 15u) * 16u + 3u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 
     if constexpr (FUSED) {
         // ---- single-launch form: place, stuff and write this chunk's stream ----------------------------
@@ -1772,6 +1793,8 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
         const uint32_t pred8 = c ? ((gb.last >> 23) & 0xFFu) : 0u;
         StuffParams sp;
         sp.slots = p.slots;
+        sp.slot_words = p.slot_words;
+        sp.img_flags = nullptr;
         sp.chunk_bits = p.chunk_bits;
         sp.bit_off = nullptr;
         sp.chunk_ff = nullptr;
@@ -1907,7 +1930,7 @@ __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_count(StuffParams p_
     const int lane = threadIdx.x & 63;
     const uint32_t gid = blockIdx.x * kStuffWaves + (threadIdx.x >> 6);
     if (gid >= n_chunks) return;
-    const uint32_t* S = p.slots + (uint64_t)gid * kSlotWords;
+    const uint32_t* S = p.slots + (uint64_t)gid * p.slot_words;
     // The first kStuffDepth steps' words are requested before the chunk's bit count and offset are known
     // (their addresses depend on neither), so a photographic chunk costs one memory round trip, not one
     // for the counts and one per step.  Words behind the chunk's end are read (the slot is always large
@@ -1945,7 +1968,7 @@ __global__ __launch_bounds__(64 * kStuffWaves) void k_stuff_write(StuffParams p_
     const int lane = threadIdx.x & 63;
     const uint32_t gid = blockIdx.x * kStuffWaves + (threadIdx.x >> 6);
     if (gid >= n_chunks) return;
-    const uint32_t* S = p.slots + (uint64_t)gid * kSlotWords;
+    const uint32_t* S = p.slots + (uint64_t)gid * p.slot_words;
     uint4 w[kStuffDepth];
     uint32_t w4[kStuffDepth];
     request_chunk<SPEC>(S, lane, w, w4);  // ahead of the counts and offsets, as in k_stuff_count
@@ -1985,7 +2008,7 @@ __global__ __launch_bounds__(64 * kImageWaves) void k_stuff_image(StuffParams p)
         const uint32_t c = c0 + wave;
         const bool have = c < p.cpi;  // the image's last round may be short; its idle waves still meet the barrier
         const uint32_t gid = first + (have ? c : p.cpi - 1u);
-        const uint32_t* S = p.slots + (uint64_t)gid * kSlotWords;
+        const uint32_t* S = p.slots + (uint64_t)gid * p.slot_words;
         uint4 w[kStuffDepth];
         uint32_t w4[kStuffDepth];
         if (have) request_chunk<SPEC>(S, lane, w, w4);
@@ -2034,7 +2057,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_stuff_image_flags(StuffParams p)
     for (uint32_t c0 = 0; c0 + wave < p.cpi; c0 += WAVES) {
         const uint32_t c = c0 + wave;
         const uint32_t gid = first + c;
-        const uint32_t* S = p.slots + (uint64_t)gid * kSlotWords;
+        const uint32_t* S = p.slots + (uint64_t)gid * p.slot_words;
         uint4 w[kStuffDepth];
         uint32_t w4[kStuffDepth];
         request_chunk<SPEC>(S, lane, w, w4);

@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libjpegenc.so")
 
-OK, E_BAD_ARG, E_TOO_SMALL, E_HIP, E_UNSUPPORTED, E_NOMEM, E_STATE, E_LIMIT = 0, -1, -2, -3, -4, -5, -6, -7
+OK, E_BAD_ARG, E_TOO_SMALL, E_HIP, E_UNSUPPORTED, E_NOMEM, E_STATE, E_LIMIT, E_AGAIN = 0, -1, -2, -3, -4, -5, -6, -7, -8
 NOALLOC_MAX_CHUNKS = 2048
 HOST_PTRS, DEVICE_PTRS = 0, 1
 PAD_EDGES = 4
@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "jpegenc_encode_stripes", "jpegenc_image_coeffs", "jpegenc_encode_coeffs", "jpegenc_reset",
     "jpegenc_push_pixel", "jpegenc_push_pixels", "jpegenc_end_of_file", "jpegenc_read_words",
     "jpegenc_words_to_bytes", "jpegenc_set_profiling", "jpegenc_kernel_times", "jpegenc_kernel_name",
-    "jpegenc_set_workspace_limit", "jpegenc_set_region_mode", "jpegenc_region_stats", "jpegenc_set_pipeline", "jpegenc_reserve", "jpegenc_segment_encode", "jpegenc_segment_count",
+    "jpegenc_set_workspace_limit", "jpegenc_set_slot_mode", "jpegenc_workspace_bytes", "jpegenc_set_region_mode", "jpegenc_region_stats", "jpegenc_set_pipeline", "jpegenc_reserve", "jpegenc_segment_encode", "jpegenc_segment_count",
     "jpegenc_segment_write", "jpegenc_segment_encode_dev", "jpegenc_segment_count_dev", "jpegenc_segment_write_dev", "jpegenc_strerror", "jpegenc_last_error", "jpegenc_version",
 ]
 
@@ -98,6 +98,9 @@ def load_library(path=None):
     L.jpegenc_kernel_name.argtypes = [i32]
     L.jpegenc_kernel_name.restype = C.c_char_p
     L.jpegenc_set_workspace_limit.argtypes = [vp, sz]
+    L.jpegenc_set_slot_mode.argtypes = [vp, i32]
+    L.jpegenc_workspace_bytes.argtypes = [vp]
+    L.jpegenc_workspace_bytes.restype = sz
     L.jpegenc_reserve.argtypes = [vp, i32, i32, i32]
     L.jpegenc_set_region_mode.argtypes = [vp, i32]
     L.jpegenc_set_pipeline.argtypes = [vp, i32]
@@ -185,6 +188,16 @@ class JpegTop:
 
     def set_workspace_limit(self, nbytes):
         self._check(self.lib.jpegenc_set_workspace_limit(self._ctx, int(nbytes)))
+
+    SLOTS_WORST_CASE, SLOTS_ADAPTIVE = 0, 1
+
+    def set_slot_mode(self, mode):
+        """SLOTS_WORST_CASE (default) or SLOTS_ADAPTIVE: scratch per group of 64 blocks sized from the longest group
+        seen so far; images of a call that outgrows it come back with status E_AGAIN (device-pointer calls)."""
+        self._check(self.lib.jpegenc_set_slot_mode(self._ctx, int(mode)))
+
+    def workspace_bytes(self):
+        return int(self.lib.jpegenc_workspace_bytes(self._ctx))
 
     REGIONS_AUTO, REGIONS_SMALL, REGIONS_LARGE = 0, 1, 2
 

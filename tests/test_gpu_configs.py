@@ -511,3 +511,69 @@ def test_single_launch_calls_of_two_contexts_share_the_gpu():
                         assert torch.equal(d_res, want[name][1]) and torch.equal(d_words, want[name][0])
                     outs[name].clear()
         torch.cuda.synchronize()
+
+
+def test_slots_sized_from_experience():
+    """JPEGENC_SLOTS_ADAPTIVE: same words as with worst-case slots from a fraction of the workspace; content whose
+    chunks outgrow the slots comes back flagged per image (device pointers) and fits when the call is repeated, and
+    is repeated by the library itself for host pointers."""
+    pkg = load_pkg()
+    dev = torch.device("cuda:0")
+    h, w, n = 1080, 1920, 24  # 24 x 507 chunks: a large call
+    natural = pkg.synth.natural_like_torch(n, h, w, 4100, dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(9)
+    noise = torch.randint(0, 256, (n, h, w, 3), generator=g, device=dev, dtype=torch.uint8)
+    mixed = natural.clone()
+    mixed[5] = noise[5]
+    cap = w * h * 6 // 4
+
+    def run(e, frames):
+        d_words = torch.zeros((n, cap), dtype=torch.int32, device=dev)
+        d_res = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
+        e.encode_batch_device(frames.data_ptr(), n, w, h, w * 3, h * w * 3, d_words.data_ptr(), cap, d_res.data_ptr())
+        torch.cuda.synchronize()
+        return d_words, d_res.cpu().numpy().view(pkg.RESULT_DTYPE).reshape(n)
+
+    def same(a, ra, b, rb, which):
+        for i in which:
+            assert ra[i].tobytes() == rb[i].tobytes(), i
+            k = int(ra[i]["n_full_words"]) + 1
+            assert torch.equal(a[i, :k], b[i, :k]), i
+
+    with pkg.JpegTop(stream=torch.cuda.current_stream().cuda_stream) as ref, \
+            pkg.JpegTop(stream=torch.cuda.current_stream().cuda_stream) as e:
+        e.set_slot_mode(e.SLOTS_ADAPTIVE)
+        want_nat, rn = run(ref, natural)
+        want_noise, rz = run(ref, noise)
+        want_mixed, rm = run(ref, mixed)
+        assert (rn["status"] == 0).all() and (rz["status"] == 0).all() and (rm["status"] == 0).all()
+        worst_bytes = ref.workspace_bytes()
+        for _ in range(2):
+            got, r = run(e, natural)
+            same(got, r, want_nat, rn, range(n))
+        assert e.workspace_bytes() * 2 < worst_bytes  # (the first nine frames went through with worst-case slots)
+        # one frame of noise among the photographs: that image is flagged, the others are right
+        got, r = run(e, mixed)
+        assert int(r[5]["status"]) == pkg.E_AGAIN and (np.delete(r["status"], 5) == 0).all()
+        same(got, r, want_mixed, rm, [i for i in range(n) if i != 5])
+        got, r = run(e, mixed)  # repeated: the context has seen the long chunks
+        same(got, r, want_mixed, rm, range(n))
+        got, r = run(e, noise)
+        same(got, r, want_noise, rz, range(n))
+        # and back: the slots stay large for a while, the output is the same
+        got, r = run(e, natural)
+        same(got, r, want_nat, rn, range(n))
+    # host pointers: the library repeats the call itself
+    with pkg.JpegTop() as e:
+        e.set_slot_mode(e.SLOTS_ADAPTIVE)
+        host_nat, host_noise = natural[:6].cpu().numpy(), noise[:6].cpu().numpy()
+        words, res = e.encode_batch(host_nat)
+        assert (res["status"] == 0).all()
+        words, res = e.encode_batch(host_noise)
+        assert (res["status"] == 0).all()
+        for i in (0, 5):
+            k = int(rz[i]["n_full_words"]) + (1 if rz[i]["tail_bits"] else 0)
+            assert np.array_equal(words[i], want_noise[i, :k].cpu().numpy().view(np.uint32))
+        one, r = O.encode(host_noise[3])
+        assert np.array_equal(words[3], one)
