@@ -577,3 +577,53 @@ def test_slots_sized_from_experience():
             assert np.array_equal(words[i], want_noise[i, :k].cpu().numpy().view(np.uint32))
         one, r = O.encode(host_noise[3])
         assert np.array_equal(words[3], one)
+
+
+def test_256_frames_of_3840x2160_in_one_call():
+    """The 256 x 3840x2160 configuration at its full count, device resident, one call (one 16-wave stuffing workgroup
+    per image): four frames word for word against the oracle, every frame through what holds at any size -- status,
+    no 0xFF byte left unstuffed, sizes consistent with each other, equal images giving equal streams wherever they
+    sit in the batch."""
+    pkg = load_pkg()
+    dev = torch.device("cuda:0")
+    h, w, n = 2160, 3840, 256
+    frames = torch.empty((n, h, w, 3), dtype=torch.uint8, device=dev)
+    for s in range(0, n, 8):
+        frames[s:s + 8] = pkg.synth.natural_like_torch(8, h, w, 100 + s, dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    frames[77, 500:900, 1000:2600] = torch.randint(0, 256, (400, 1600, 3), generator=g, device=dev, dtype=torch.uint8)
+    twins = {130: 5, 255: 77, 201: 5}  # copies of earlier frames, the noisy one among them
+    for dst, src in twins.items():
+        frames[dst] = frames[src]
+    cap = w * h * 3 // 4
+    d_words = torch.zeros((n, cap), dtype=torch.int32, device=dev)
+    d_res = torch.zeros((n, 32), dtype=torch.uint8, device=dev)
+    with pkg.JpegTop(stream=torch.cuda.current_stream().cuda_stream) as e:
+        e.encode_batch_device(frames.data_ptr(), n, w, h, w * 3, h * w * 3, d_words.data_ptr(), cap, d_res.data_ptr())
+        torch.cuda.synchronize()
+    res = d_res.cpu().numpy().view(pkg.RESULT_DTYPE).reshape(n)
+    assert (res["status"] == 0).all()
+    # sizes: stuffed bytes = whole unstuffed bytes + stuffed zeros >= the former; words and tail from the stuffed bits
+    sbits = res["total_bytes_stuffed"].astype(np.int64) * 8 + (res["total_bits_unstuffed"].astype(np.int64) & 7)
+    assert (res["total_bytes_stuffed"] >= res["total_bits_unstuffed"] // 8).all()
+    assert (res["n_full_words"] == sbits >> 5).all() and (res["tail_bits"] == (sbits & 31)).all()
+    assert (res["eof_partial_ready"] == (res["tail_bits"] != 0)).all()
+    for i in range(n):  # stuffing, on the GPU: every 0xFF byte of the stream is followed by 0x00
+        k = int(res[i]["total_bytes_stuffed"])
+        wv = d_words[i, :(k + 3) // 4]
+        by = torch.stack([(wv >> 24) & 0xFF, (wv >> 16) & 0xFF, (wv >> 8) & 0xFF, wv & 0xFF], dim=1).reshape(-1)[:k]
+        ff = by[:-1] == 0xFF
+        assert bool((by[1:][ff] == 0).all()) and int(by[-1]) != 0xFF, i
+        zeros = int(ff.sum())
+        assert k == int(res[i]["total_bits_unstuffed"]) // 8 + zeros, i
+    for dst, src in twins.items():
+        assert res[dst].tobytes() == res[src].tobytes()
+        k = int(res[src]["n_full_words"]) + 1
+        assert torch.equal(d_words[dst, :k], d_words[src, :k])
+    checked = (0, 77, 128, 254)
+    host = {i: frames[i].cpu().numpy() for i in checked}
+    got = {i: d_words[i, :int(res[i]["n_full_words"]) + (1 if res[i]["tail_bits"] else 0)].cpu().numpy().view(np.uint32)
+           for i in checked}
+    with ThreadPoolExecutor(4) as pool:
+        list(pool.map(lambda i: same_as_oracle(got[i], res[i], host[i]), checked))

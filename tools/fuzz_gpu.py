@@ -58,11 +58,31 @@ def main():
             # launch structure and LDS region size change the speed only: any combination must give the same words
             e.set_pipeline(int(rng.integers(0, 3)))
             e.set_region_mode(int(rng.integers(0, 3)))
+            # chunk slots sized from the calls before (host-pointer calls repeat themselves when a chunk outgrows them)
+            e.set_slot_mode(int(rng.integers(0, 2)))
             for _ in range(4):
                 h, w = 8 * int(rng.integers(1, 40)), 8 * int(rng.integers(1, 70))
-                if rng.random() < 0.03:  # now and then a big one: thousands of chunks, long prefix sums
+                big = rng.random() < 0.04
+                if big:  # now and then a big one: thousands of chunks, long prefix sums
                     h, w = 8 * int(rng.integers(100, 140)), 8 * int(rng.integers(200, 260))
-                mode = rng.integers(0, 4)
+                mode = rng.integers(0, 5)
+                if mode == 4:  # coefficients straight into the coders (any 11-bit values; the context's tables play no part)
+                    hh, ww = (h, w) if not big else (8 * int(rng.integers(1, 40)), 8 * int(rng.integers(1, 70)))
+                    nb = (hh // 8) * (ww // 8)
+                    dens = float(rng.choice([0.02, 0.1, 0.4, 1.0]))
+                    c = rng.integers(-1024, 1024, (nb, 3, 64)) * (rng.random((nb, 3, 64)) < dens)
+                    c[rng.random((nb, 3, 64)) < 0.002] = -1024
+                    c = c.astype(np.int16)
+                    got, res = e.encode_coeffs(c, ww, hh)
+                    want, r = O.encode_coeffs(c, O.default_config(cb_6d64=kw["cb_6d64"]))
+                    if not (np.array_equal(got, want) and int(res["tail_bits"]) == r.tail_bits
+                            and int(res["total_bytes_stuffed"]) == r.total_bytes_stuffed):
+                        np.save("gpurun_out/fuzz_fail_coeffs.npy", c)
+                        print("COEFFS MISMATCH", hh, ww, dens, kw)
+                        sys.exit(1)
+                    n += 1
+                    px += hh * ww
+                    continue
                 if mode == 3 and h >= 16:  # one stream from bands (fresh contexts, same configuration)
                     img = image(rng, h, w)
                     cuts = sorted(set([0, h] + [8 * int(c) for c in rng.integers(1, h // 8, int(rng.integers(1, 4)))]))
@@ -95,7 +115,7 @@ def main():
                     nimg = ns
                     h = rows
                 else:
-                    nimg = int(rng.integers(1, 4))
+                    nimg = int(rng.integers(1, 4)) if not big else int(rng.integers(1, 9))  # (up to 4500 chunks)
                     imgs = None
                 if imgs is None:
                     imgs = np.stack([image(rng, h, w) for _ in range(nimg)])
