@@ -281,8 +281,12 @@ def main():
                     per_frame = pmc.get("k_encode_chunks_hbm_bytes_per_frame")
                     valu = pmc.get("valu", {})
                     ipw = valu.get("valu_instructions_per_wave")
+                    built = enc.lib.jpegenc_version().decode().split()[-1]
                     line["roofline"]["from_stored_profile"] = {
                         "source": "profiles/pmc_traffic.json (%s)" % pmc.get("build", "rocprofv3 --pmc passes"),
+                        # which kernel sources the counters were collected on, and whether this run's library is that build
+                        "profile_commit": pmc.get("commit"), "profile_kernels_sha": pmc.get("kernels_sha"),
+                        "library_kernels_sha": built, "stale": pmc.get("kernels_sha") != built,
                         "traffic": round(per_frame * nf / launches_per_step) if per_frame else None,
                         "valu_insts_per_wave": ipw,
                         "lane_ops_per_pixel": round(ipw * 64 / 4096.0, 1) if ipw else None,

@@ -315,6 +315,7 @@ int jpegenc_reserve(jpegenc_ctx* ctx, int n_images, int w, int h);
 const char* jpegenc_strerror(int code);
 /* Text of the last HIP error seen by this context ("" if none). */
 const char* jpegenc_last_error(const jpegenc_ctx* ctx);
+/* "jpegenc-gfx950 <version> kernels <first 12 hex digits of the SHA-1 of the kernel sources it was built from>" */
 const char* jpegenc_version(void);
 
 #ifdef __cplusplus

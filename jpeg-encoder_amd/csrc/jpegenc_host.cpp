@@ -1469,6 +1469,9 @@ const char* jpegenc_strerror(int code) {
 
 const char* jpegenc_last_error(const jpegenc_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 
-const char* jpegenc_version(void) { return "jpegenc-gfx950 0.1"; }
+#ifndef JPEGENC_KERNELS_SHA
+#define JPEGENC_KERNELS_SHA "unknown"
+#endif
+const char* jpegenc_version(void) { return "jpegenc-gfx950 0.3 kernels " JPEGENC_KERNELS_SHA; }
 
 }  // extern "C"

@@ -5,7 +5,7 @@ tag=$1; frames=$2; shift; shift
 export TMPDIR=/tmp
 # the counter list goes into the log first: a profiler that dies names no counters itself
 echo "counters: $*" > gpurun_out/pmc_${tag}.log
-timeout -s KILL 150 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_${tag} -- python3 bench.py --frames $frames --steps 2 --warmup 1 --no-cpu --no-profile $PMC_BENCH_ARGS >> gpurun_out/pmc_${tag}.log 2>&1
+timeout -s KILL 280 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_${tag} -- python3 bench.py --frames $frames --steps 2 --warmup 1 --no-cpu --no-profile $PMC_BENCH_ARGS >> gpurun_out/pmc_${tag}.log 2>&1
 echo "rc=$?"
 python3 - <<PY
 import csv, glob, collections
