@@ -4,7 +4,7 @@
 # default "--frames 768").  Leaves the last build installed.
 for v in "$@"; do
   cp ab/$v.so jpeg-encoder_amd/libjpegenc.so
-  timeout -k 10 200 python -u bench.py ${CMP_ARGS:---frames 768} --steps 10 --warmup 3 --no-cpu > gpurun_out/cmp_$v.log 2>&1 || true
+  timeout -k 10 200 python -u bench.py ${CMP_ARGS:---frames 768} --steps 10 --warmup 3 --no-cpu > gpurun_out/cmp_$v.log 2>&1 || { echo "$v failed: stopping"; exit 1; }
   python - <<PY
 import json
 l=[x for x in open("gpurun_out/cmp_$v.log") if x.startswith("{")][-1]
