@@ -44,7 +44,7 @@ def parse_args():
                     help="octave amplitude ratio of the natural-like generator (default 0.7; larger = more detail)")
     ap.add_argument("--quant", type=int, default=1, help="every quantiser table entry (1: the RTL default)")
     ap.add_argument("--ws-mb", type=int, default=0, help="workspace limit in MiB (0: library default)")
-    ap.add_argument("--regions", choices=["auto", "small", "large"], default="auto",
+    ap.add_argument("--regions", choices=["auto", "small", "large", "short"], default="auto",
                     help="LDS staging regions of the encode kernel (jpegenc_set_region_mode)")
     ap.add_argument("--slots", choices=["adaptive", "worst"], default="adaptive",
                     help="scratch per chunk: sized from the chunk lengths of earlier calls, or the worst case (jpegenc_set_slot_mode)")
@@ -173,7 +173,8 @@ def main():
 
     if args.ws_mb:
         enc.set_workspace_limit(args.ws_mb << 20)
-    enc.set_region_mode({"auto": enc.REGIONS_AUTO, "small": enc.REGIONS_SMALL, "large": enc.REGIONS_LARGE}[args.regions])
+    enc.set_region_mode({"auto": enc.REGIONS_AUTO, "small": enc.REGIONS_SMALL, "large": enc.REGIONS_LARGE,
+                         "short": enc.REGIONS_SHORT}[args.regions])
     if args.split:
         enc.set_pipeline(enc.PIPELINE_SPLIT)
     if args.slots == "adaptive":
@@ -245,9 +246,12 @@ def main():
         "workspace": {"slots": args.slots, "bytes": enc.workspace_bytes(),
                       "bytes_per_frame": round(enc.workspace_bytes() / float(nf))},
     }
-    over_small, over_large, counted = enc.region_stats()
-    if counted:  # chunks of the last counted launch that hold an MCU too long for a small / large LDS region
-        line["chunks_over_region"] = {"small": round(over_small / counted, 4), "large": round(over_large / counted, 4)}
+    over_small, over_large, counted, over_short, auto_at = enc.region_stats()
+    if counted:  # chunks of the last counted launch that hold an MCU too long for a short / small / large LDS region
+        line["chunks_over_region"] = {"short": round(over_short / counted, 4), "small": round(over_small / counted, 4),
+                                      "large": round(over_large / counted, 4)}
+        line["regions"] = args.regions if args.regions != "auto" else \
+            "auto: " + {enc.REGIONS_SMALL: "small", enc.REGIONS_LARGE: "large", enc.REGIONS_SHORT: "short"}.get(auto_at, "?")
     failed = not ok
     if rank == 0:
         # Rooflines from the live HIP-event durations of this run (events recorded by the library on its stream).

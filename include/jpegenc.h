@@ -292,19 +292,25 @@ int jpegenc_set_pipeline(jpegenc_ctx* ctx, int mode);
  * twelve wavefronts share a compute unit and are right for photographic content up to about 2.5 bytes per
  * pixel; a group of 64 blocks that holds a longer block is coded twice.  Large regions (2272 bits, more than
  * a block of uniform noise needs on average) leave room for eight wavefronts and cost 15 % where small ones
- * suffice.  AUTO (default): the kernel counts, in every launch, the groups with a block too long for a small
- * and for a large region, and the context uses for the next launches whichever size those counts make
- * cheaper (large from about 3 to 4 % of the groups too long for small regions on, at once; back to small
- * after four launches in a row whose counts favour it). */
+ * suffice.  Short regions (1024 bits) let sixteen wavefronts share a compute unit: 1 % faster than small ones
+ * where no block is longer (content up to about 1.5 bytes per pixel).  AUTO (default): the kernel counts, in
+ * every launch, the groups with a block too long for a short, a small and a large region, and the context uses
+ * for the next launches whichever size those counts make cheaper (large from about 3 to 4 % of the groups too
+ * long for small regions on, at once; back to small after four launches in a row whose counts favour it; short
+ * after four launches in a row with fewer than one group in 1024 too long for it, back to small from one in
+ * 256 on, at once). */
 #define JPEGENC_REGIONS_AUTO 0
 #define JPEGENC_REGIONS_SMALL 1
 #define JPEGENC_REGIONS_LARGE 2
+#define JPEGENC_REGIONS_SHORT 3
 int jpegenc_set_region_mode(jpegenc_ctx* ctx, int mode);
 /* The counts behind that choice, as the last finished launch that collected them left them (calls of at most
  * 2048 groups and calls with quantisation tables or unaligned rows collect none): counts[0] = groups of 64
  * blocks with a block too long for a small region, counts[1] = with one too long for a large region,
- * counts[2] = groups of that launch.  Read after jpegenc_synchronize for figures of a particular call. */
-int jpegenc_region_stats(jpegenc_ctx* ctx, uint64_t counts[3]);
+ * counts[2] = groups of that launch, counts[3] = groups with a block too long for a short region; counts[4] =
+ * the size the context's next launch in AUTO mode starts from (JPEGENC_REGIONS_SMALL / _LARGE / _SHORT).  Read
+ * after jpegenc_synchronize for figures of a particular call. */
+int jpegenc_region_stats(jpegenc_ctx* ctx, uint64_t counts[5]);
 
 /* Grows the workspace now to what jpegenc_encode_batch(n_images, w, h) will need (under the limit
  * above), so that later device-pointer calls of at most that size only enqueue work: no allocation, no

@@ -120,8 +120,9 @@ struct jpegenc_ctx {
     // the chunks that hold an MCU too long for a small region; the counts reach `stats_host` (pinned) by an
     // asynchronous copy behind the launch and steer the launches after it.
     int region_mode = JPEGENC_REGIONS_AUTO;
-    bool large_regions = false;
+    uint32_t regions = jpegenc::kRegionsSmall;  // what AUTO stands at
     int small_votes = 0;  // launches in a row whose counts favoured small regions while large ones were in use
+    int short_votes = 0;  // launches in a row without an MCU too long for a short region while small ones were in use
     DevBuf<uint32_t> stats;  // [kEncodeStatsWords] + one flag word per image of a launch group (img_flags)
     uint32_t* stats_host = nullptr;
 
@@ -375,7 +376,7 @@ int workspace_used(jpegenc_ctx* ctx) {
 // rows, all-ones tables) exists with large regions.
 int choose_regions(jpegenc_ctx* ctx, EncodeParams* ep, int align, uint64_t chunks, uint32_t n_images) {
     ep->stats = nullptr;
-    ep->large_regions = 0;
+    ep->regions = kRegionsSmall;
     ep->report_bits = 0xFFFFFFFFu;
     ep->stats_seq = 0;
     const bool common = !ctx->quant && align >= 8;
@@ -384,19 +385,20 @@ int choose_regions(jpegenc_ctx* ctx, EncodeParams* ep, int align, uint64_t chunk
     if (common && chunks <= kSingleLaunchMaxChunks && ctx->region_mode == JPEGENC_REGIONS_AUTO) {
         // every chunk is resident at once even with large regions: they cost nothing here, and a small call is
         // spared the two stream operations of the statistics
-        ep->large_regions = 1;
+        ep->regions = kRegionsLarge;
         return JPEGENC_OK;
     }
     if (common && ctx->region_mode == JPEGENC_REGIONS_AUTO) {
         // whatever the last completed copy left in the pinned words: a heuristic, any value is safe
         const volatile uint32_t* h = ctx->stats_host;
-        uint64_t over_small = 0, over_large = 0;
+        uint64_t over_short = 0, over_small = 0, over_large = 0;
         for (int i = 0; i < 16; ++i) {
             over_small += h[16 * i];
             over_large += h[16 * i + 1];
+            over_short += h[16 * i + 4];
         }
         const uint64_t total = h[16 * 16];
-        if (total >= 256 && over_large <= over_small && over_small <= total) {
+        if (total >= 256 && over_large <= over_small && over_small <= over_short && over_short <= total) {
             // A chunk with an MCU too long for its region is coded again, and the other waves of its workgroup
             // (four with small regions, two with large ones) hold their LDS idle meanwhile: a workgroup with any
             // such chunk costs about 2.15 times one without.  Large regions cost every chunk about 15 % (two waves
@@ -409,17 +411,35 @@ int choose_regions(jpegenc_ctx* ctx, EncodeParams* ep, int align, uint64_t chunk
             // content: 1.15 times), so the way up is taken at once and the way down only after four launches in a
             // row that ask for it: a caller that alternates between kinds of content stays on large regions.
             if (small_cost > large_cost * 1.02) {
-                ctx->large_regions = true;
-                ctx->small_votes = 0;
-            } else if (ctx->large_regions && small_cost * 1.02 < large_cost && ++ctx->small_votes >= 4) {
-                ctx->large_regions = false;
-                ctx->small_votes = 0;
+                ctx->regions = kRegionsLarge;
+                ctx->small_votes = ctx->short_votes = 0;
+            } else if (ctx->regions == kRegionsLarge) {
+                if (small_cost * 1.02 < large_cost && ++ctx->small_votes >= 4) {
+                    ctx->regions = kRegionsSmall;
+                    ctx->small_votes = ctx->short_votes = 0;
+                }
+            } else if (ctx->regions == kRegionsShort) {
+                // Short regions gain 1 % and lose 15 % with 6 % of the chunks redone: they are left as soon as one
+                // chunk in 256 holds an MCU too long for them ...
+                if (over_short * 256 > total) {
+                    ctx->regions = kRegionsSmall;
+                    ctx->short_votes = 0;
+                }
+            } else {
+                // ... and taken after four launches in a row with fewer than one in 1024
+                ctx->short_votes = over_short * 1024 < total ? ctx->short_votes + 1 : 0;
+                if (ctx->short_votes >= 4) {
+                    ctx->regions = kRegionsShort;
+                    ctx->short_votes = 0;
+                }
             }
         }
     } else if (common) {
-        ctx->large_regions = ctx->region_mode == JPEGENC_REGIONS_LARGE;
+        ctx->regions = ctx->region_mode == JPEGENC_REGIONS_LARGE   ? kRegionsLarge
+                       : ctx->region_mode == JPEGENC_REGIONS_SHORT ? kRegionsShort
+                                                                   : kRegionsSmall;
     }
-    ep->large_regions = (common && ctx->large_regions) ? 1u : 0u;
+    ep->regions = common ? ctx->regions : kRegionsSmall;
     ep->stats = ctx->stats.p;
     if (++ctx->stats_issued == 0 || uint32_t(ctx->stats_issued) == 0) ctx->stats_issued = 1;
     ep->stats_seq = uint32_t(ctx->stats_issued);
@@ -493,7 +513,7 @@ int run_group(jpegenc_ctx* ctx, const Workspace& ws, bool timed, const Plan& pl,
     if (timed && !coeffs && ctx->pipeline != JPEGENC_PIPELINE_SPLIT && uint64_t(n) * cpi <= resident && !ctx->quant &&
         align >= 8) {
         ep.stats = nullptr;
-        ep.large_regions = 1;
+        ep.regions = kRegionsLarge;
         ep.state = ctx->state.p;
         ep.generation = next_generation();
         // about a frame of 1080p or less: a lane per component block, chunks of 21 MCUs -- three times the waves
@@ -511,17 +531,17 @@ int run_group(jpegenc_ctx* ctx, const Workspace& ws, bool timed, const Plan& pl,
     int rc_regions = JPEGENC_OK;
     if (coeffs) {  // the coders of the small-region variant unless large regions are asked for; no statistics
         ep.stats = nullptr;
-        ep.large_regions = ctx->region_mode == JPEGENC_REGIONS_LARGE ? 1u : 0u;
+        ep.regions = ctx->region_mode == JPEGENC_REGIONS_LARGE ? kRegionsLarge : kRegionsSmall;
     } else if (!timed) {
         // the call that allocates nothing (possibly under graph capture): the region size the context stands at,
         // no statistics -- their memset and copy would be replayed with the graph and steer nothing
         ep.stats = nullptr;
-        ep.large_regions = 0;
+        ep.regions = kRegionsSmall;
         if (!ctx->quant && align >= 8)
-            ep.large_regions = (ctx->region_mode == JPEGENC_REGIONS_AUTO ? ctx->large_regions
-                                                                         : ctx->region_mode == JPEGENC_REGIONS_LARGE)
-                                   ? 1u
-                                   : 0u;
+            ep.regions = ctx->region_mode == JPEGENC_REGIONS_AUTO    ? ctx->regions
+                         : ctx->region_mode == JPEGENC_REGIONS_LARGE ? kRegionsLarge
+                         : ctx->region_mode == JPEGENC_REGIONS_SHORT ? kRegionsShort
+                                                                     : kRegionsSmall;
     } else {
         rc_regions = choose_regions(ctx, &ep, align, uint64_t(n) * cpi, n);
     }
@@ -1417,20 +1437,24 @@ int jpegenc_set_pipeline(jpegenc_ctx* ctx, int mode) {
     return JPEGENC_OK;
 }
 
-int jpegenc_region_stats(jpegenc_ctx* ctx, uint64_t counts[3]) {
+int jpegenc_region_stats(jpegenc_ctx* ctx, uint64_t counts[5]) {
     if (!ctx || !counts) return JPEGENC_E_BAD_ARG;
     const volatile uint32_t* h = ctx->stats_host;
-    counts[0] = counts[1] = 0;
+    counts[0] = counts[1] = counts[3] = 0;
     for (int i = 0; i < 16; ++i) {
         counts[0] += h[16 * i];
         counts[1] += h[16 * i + 1];
+        counts[3] += h[16 * i + 4];
     }
     counts[2] = h[16 * 16];
+    counts[4] = ctx->regions == kRegionsLarge   ? JPEGENC_REGIONS_LARGE
+                : ctx->regions == kRegionsShort ? JPEGENC_REGIONS_SHORT
+                                                : JPEGENC_REGIONS_SMALL;
     return JPEGENC_OK;
 }
 
 int jpegenc_set_region_mode(jpegenc_ctx* ctx, int mode) {
-    if (!ctx || mode < JPEGENC_REGIONS_AUTO || mode > JPEGENC_REGIONS_LARGE) return JPEGENC_E_BAD_ARG;
+    if (!ctx || mode < JPEGENC_REGIONS_AUTO || mode > JPEGENC_REGIONS_SHORT) return JPEGENC_E_BAD_ARG;
     ctx->region_mode = mode;
     return JPEGENC_OK;
 }

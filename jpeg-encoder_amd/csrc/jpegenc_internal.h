@@ -85,10 +85,11 @@ struct EncodeParams {
                            // 0, 16, ..., 240 count the chunks that hold an MCU too long for a small LDS region,
                            // words 1, 17, ..., 241 those with one too long even for a large region, words 2, 18,
                            // ... the longest chunk among those above report_bits (0: none), words 3, 19, ... the
-                           // chunks left unstored; word 256 receives the launch's chunk count, word 257 its
+                           // chunks left unstored, words 4, 20, ... the chunks with an MCU too long for a short
+                           // region; word 256 receives the launch's chunk count, word 257 its
                            // report_bits, word 258 its slot_words, word 259
                            // its stats_seq
-    uint32_t large_regions;  // 1: the kernel variant with large LDS regions (8 workgroups per CU instead of 12)
+    uint32_t regions;      // kRegionsSmall / kRegionsLarge / kRegionsShort: which kernel variant (size of the LDS regions)
     // Single-launch form (small launches only, `state` != nullptr): every chunk's wave goes on to find its place
     // in the image's stream from the hand-off words of the chunks before it, stuffs its stream and writes the
     // words.  state = [3][n_images * cpi] words of tag << 32 | payload, tag = `generation` (never 0, never reused:
@@ -105,6 +106,8 @@ struct EncodeParams {
 constexpr uint32_t kSingleLaunchMaxChunks = 2048;
 constexpr uint32_t kWideChunkMcus = 21;  // MCUs per chunk with a lane per component block
 constexpr int kEncodeStatsWords = 16 * 16 + 16;
+// EncodeParams::regions: small = 12 waves per CU, large = 8 (long strings), short = 16 (short strings)
+constexpr uint32_t kRegionsSmall = 0, kRegionsLarge = 1, kRegionsShort = 2;
 
 struct ScanParams {
     const uint32_t* counts;  // [n_images][cpi]

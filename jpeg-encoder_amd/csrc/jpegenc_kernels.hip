@@ -1270,7 +1270,14 @@ __device__ __forceinline__ Gathered gather_states(const uint64_t* st, uint32_t c
 // ------------------------------------------------------------------------------------------------
 // LDS budget: per wave 64 regions of REGION words (one per lane, for the first pass), per workgroup one Huffman
 // table.  The first pass gives every lane one region; if any lane overflows, the chunk is redone with regions cut
-// to the lengths the first pass has counted.  Three sizes, measured on 1080p batches:
+// to the lengths the first pass has counted.  Four sizes, measured on 1080p batches:
+//   short  34 words (32 usable = 1024 bits per MCU, 2.0 bytes per pixel), four waves per workgroup, four workgroups =
+//          sixteen waves per CU (four per SIMD, 128 registers: eight values that are only needed at the wave's start
+//          and end live in scratch).  The add / logic / right-shift kind of instruction issues faster with four
+//          waves on a SIMD than with three: 1.0 to 1.4 % faster than small regions where no MCU exceeds 1024 bits
+//          (content up to about 1.5 bytes per pixel), 15 % slower with 6 % of the chunks redone (1.8 bytes per
+//          pixel), three times slower when every chunk is.  (33 words: the same; eight waves per workgroup with 36
+//          words: 4 % slower than small.)
 //   small  46 words (44 usable = 1408 bits per MCU, 2.75 bytes per pixel), four waves per workgroup sharing the
 //          table (eight-byte entries): three workgroups = twelve waves per CU (three per SIMD).  Enough for
 //          photographic content.  (47 words with the table split into a word and a byte array: 2 % slower; 41 words
@@ -1281,7 +1288,7 @@ __device__ __forceinline__ Gathered gather_states(const uint64_t* st, uint32_t c
 //          noise, 2150 bits per MCU on average, is done in one pass: 181 against 85 Gpixel/s with 65 words).
 //          (Four waves per workgroup: 8 % slower; one wave, seven per CU: 7 % slower.)
 //   single-launch form: 65 words, one wave per workgroup, eight per CU, which is what makes 2048 chunks resident.
-// The host picks small or large per launch from the overflow counts of its previous launches (see
+// The host picks short, small or large per launch from the overflow counts of its previous launches (see
 // EncodeParams::stats).  The variants off the common path (quantising: short streams; rows not 8-byte aligned)
 // keep 41 words and one wave per workgroup, twelve per CU: with 47 words they would spill registers.  Odd region
 // strides keep lanes on different LDS banks.
@@ -1292,9 +1299,10 @@ __device__ __forceinline__ Gathered gather_states(const uint64_t* st, uint32_t c
 #ifndef JPEGENC_HTAB8
 #define JPEGENC_HTAB8 46
 #endif
-[[maybe_unused]] constexpr int kRegionBasic = 41, kRegionSmall = JPEGENC_HTAB8 ? JPEGENC_HTAB8 : 47, kRegionFused = 65, kRegionLarge = 73;
-[[maybe_unused]] constexpr int kSmallWaves = 4, kLargeWaves = 2;  // per workgroup
-constexpr uint32_t kSmallRegionBits = (kRegionSmall - 2) * 32;  // what a lane may emit in a small region
+[[maybe_unused]] constexpr int kRegionShort = 34, kRegionBasic = 41, kRegionSmall = JPEGENC_HTAB8 ? JPEGENC_HTAB8 : 47, kRegionFused = 65, kRegionLarge = 73;
+[[maybe_unused]] constexpr int kSmallWaves = 4, kLargeWaves = 2;  // per workgroup (short regions: as small ones)
+constexpr uint32_t kShortRegionBits = (kRegionShort - 2) * 32;  // what a lane may emit in a short region
+constexpr uint32_t kSmallRegionBits = (kRegionSmall - 2) * 32;
 constexpr uint32_t kLargeRegionBits = (kRegionLarge - 2) * 32;
 
 // End of the range of lanes [lo, hi) that one exact-fit pass can hold: `need_incl` is the inclusive prefix
@@ -1312,7 +1320,7 @@ __device__ __forceinline__ uint32_t fit_range_end(uint32_t need_incl, uint32_t l
 // COEFFS: the checking variant that takes the coefficients at the coders' inputs (EncodeParams::coeffs) instead of
 // transforming pixels: everything from the coders on is the code of the variant it is built from.
 template <int ALIGN, bool QUANT, bool WRAP, int REGION, bool FUSED, int WAVES, int LPM = 1, bool COEFFS = false>
-__global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_encode_chunks(EncodeParams p) {
+__global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : REGION == kRegionShort ? 4 : 3) void k_encode_chunks(EncodeParams p) {
     static_assert(LPM == 1 || (LPM == 3 && FUSED && !QUANT && ALIGN == 8), "one lane per block exists for the single-launch form only");
     static_assert(!COEFFS || (!QUANT && !FUSED && LPM == 1), "coefficients feed the coder that reads pairs");
     constexpr int kMcus = LPM == 3 ? 21 : kChunkMcus;  // MCUs per chunk
@@ -1327,7 +1335,7 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
     static_assert(kPrivWords % 4 == 0, "every wave's part starts on a 16-byte boundary");
     static_assert(63 * kRegionWords + kMaxMcuWords <= kPrivWords, "first-pass overrun of the last lane");
     constexpr uint32_t kFitWords = 64 * kRegionWords;  // what the exact regions of one pass may add up to
-    static_assert(kFitWords >= 16 * (kMaxMcuWords + 2), "a pass holds at least 16 worst-case MCUs");
+    static_assert(kFitWords >= (REGION == kRegionShort ? 13 : 16) * (kMaxMcuWords + 2), "a pass holds at least 16 (short regions: 13) worst-case MCUs");
     // One wave codes one chunk in LDS of its own; the waves of a workgroup share the Huffman table only.  `flat`
     // is all of it (the bit writer's addresses count from there: a constant base costs no instruction per store),
     // `priv` this wave's part.
@@ -1337,7 +1345,7 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
     uint32_t* const priv = flat + woff;
     // the Huffman table: code << size as words, then code length + size as bytes (one array: the single-launch
     // form reuses it as the stage of the stuffing step)
-    constexpr bool kTab8 = (JPEGENC_HTAB8 != 0) && REGION == kRegionSmall && !QUANT && LPM == 1 && WAVES == kSmallWaves;
+    constexpr bool kTab8 = (JPEGENC_HTAB8 != 0) && (REGION == kRegionSmall || REGION == kRegionShort) && !QUANT && LPM == 1 && WAVES == kSmallWaves;
     __shared__ __attribute__((aligned(16))) uint32_t tables[kTab8 ? 2 * kHtabEntries : kHtabEntries + kHtabEntries / 4];
     uint32_t* const htab = tables;
     uint8_t* const hlen = reinterpret_cast<uint8_t*>(tables + kHtabEntries);
@@ -1462,7 +1470,7 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
     // the lengths of all 64 strings are known, and the chunk is redone with every lane given exactly the
     // words it needs (`fit`): in one more pass when the whole chunk fits the LDS, else in as few passes over
     // consecutive lane ranges [lo, hi) as the LDS allows (uniform noise: two ranges; the worst case of 156
-    // words per lane: four).  Lanes outside the range of a pass compute along and store nothing.
+    // words per lane: four, five with short regions).  Lanes outside the range of a pass compute along and store nothing.
     bool fit = false;
     uint32_t lo = 0, hi = 64;             // lanes coded by this pass (uniform)
     // fit: the words of every lane's region wait in the LDS behind the regions (the room of the first pass's
@@ -1620,13 +1628,17 @@ __global__ __launch_bounds__(64 * WAVES, REGION >= kRegionFused ? 2 : 3) void k_
             flat[((bw.T + 31u) >> 5) + 1u] = 0u;  // one zero word behind the string
         }
         if (!fit && p.stats) {
-            // for the host's choice of REGION: chunks with an MCU beyond the small region, spread over 16
-            // counters on lines of their own, and the launch's chunk count beside them
-            if (__any((int)(Lall > kSmallRegionBits))) {
+            // for the host's choice of REGION: chunks with an MCU beyond the short, the small and the large region,
+            // spread over 16 counters each on lines of their own, and the launch's chunk count beside them
+            if (__any((int)(Lall > kShortRegionBits))) {
                 if (lane == 0)
-                    __hip_atomic_fetch_add(&p.stats[(gid & 15u) * 16u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__any((int)(Lall > kLargeRegionBits)) && lane == 0)  // ... and even for a large one
-                    __hip_atomic_fetch_add(&p.stats[(gid & 15u) * 16u + 1u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(&p.stats[(gid & 15u) * 16u + 4u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__any((int)(Lall > kSmallRegionBits))) {
+                    if (lane == 0)
+                        __hip_atomic_fetch_add(&p.stats[(gid & 15u) * 16u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__any((int)(Lall > kLargeRegionBits)) && lane == 0)  // ... and even for a large one
+                        __hip_atomic_fetch_add(&p.stats[(gid & 15u) * 16u + 1u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
             if (gid == 0 && lane == 0) {
                 p.stats[16 * 16] = p.n_images * p.cpi;
@@ -2254,9 +2266,13 @@ hipError_t launch_encode_quant(const EncodeParams& p, dim3 grid, int align, hipS
 hipError_t launch_encode_small(const EncodeParams& p, dim3 grid, hipStream_t s) {
     return launch_encode_b<8, false, kRegionSmall, false, kSmallWaves>(p, grid, s);
 }
+hipError_t launch_encode_short(const EncodeParams& p, dim3 grid, hipStream_t s) {
+    return launch_encode_b<8, false, kRegionShort, false, kSmallWaves>(p, grid, s);
+}
 #else
 hipError_t launch_encode_quant(const EncodeParams& p, dim3 grid, int align, hipStream_t s);
 hipError_t launch_encode_small(const EncodeParams& p, dim3 grid, hipStream_t s);
+hipError_t launch_encode_short(const EncodeParams& p, dim3 grid, hipStream_t s);
 
 hipError_t launch_encode(const EncodeParams& p_in, uint32_t n_images, int align, hipStream_t s) {
     EncodeParams p = p_in;
@@ -2272,8 +2288,8 @@ hipError_t launch_encode(const EncodeParams& p_in, uint32_t n_images, int align,
         // coefficient-fed checking variants: the coders of the small-region variant (symbols joined) or of the
         // large-region one (symbol by symbol)
         if (p.state || p.qmul) return hipErrorInvalidValue;
-        return p.large_regions ? launch_encode_b<8, false, kRegionLarge, false, kLargeWaves, 1, true>(p, grid, s)
-                               : launch_encode_b<8, false, kRegionSmall, false, kSmallWaves, 1, true>(p, grid, s);
+        return p.regions == kRegionsLarge ? launch_encode_b<8, false, kRegionLarge, false, kLargeWaves, 1, true>(p, grid, s)
+                                          : launch_encode_b<8, false, kRegionSmall, false, kSmallWaves, 1, true>(p, grid, s);
     }
     if (p.state) {
         // single-launch form: only the common variant (a launch this small leaves most of the LDS unused anyway)
@@ -2284,8 +2300,9 @@ hipError_t launch_encode(const EncodeParams& p_in, uint32_t n_images, int align,
     if (p.qmul) return launch_encode_quant(p, grid, align, s);
     // large regions exist for the common variant only (8-byte-aligned rows, all-ones tables: quantised streams are short)
     if (align >= 8)
-        return p.large_regions ? launch_encode_b<8, false, kRegionLarge, false, kLargeWaves>(p, grid, s)
-                               : launch_encode_small(p, grid, s);
+        return p.regions == kRegionsLarge   ? launch_encode_b<8, false, kRegionLarge, false, kLargeWaves>(p, grid, s)
+               : p.regions == kRegionsShort ? launch_encode_short(p, grid, s)
+                                            : launch_encode_small(p, grid, s);
     if (align >= 4) return launch_encode_b<4, false, kRegionBasic>(p, grid, s);
     return launch_encode_b<1, false, kRegionBasic>(p, grid, s);
 }

@@ -199,10 +199,11 @@ class JpegTop:
     def workspace_bytes(self):
         return int(self.lib.jpegenc_workspace_bytes(self._ctx))
 
-    REGIONS_AUTO, REGIONS_SMALL, REGIONS_LARGE = 0, 1, 2
+    REGIONS_AUTO, REGIONS_SMALL, REGIONS_LARGE, REGIONS_SHORT = 0, 1, 2, 3
 
     def set_region_mode(self, mode):
-        """LDS staging regions of the encode kernel: REGIONS_AUTO (default), REGIONS_SMALL, REGIONS_LARGE; speed only."""
+        """LDS staging regions of the encode kernel: REGIONS_AUTO (default), REGIONS_SMALL, REGIONS_LARGE,
+        REGIONS_SHORT; speed only."""
         self._check(self.lib.jpegenc_set_region_mode(self._ctx, int(mode)))
 
     PIPELINE_AUTO, PIPELINE_SPLIT, PIPELINE_SINGLE_MCU = 0, 1, 2
@@ -212,11 +213,11 @@ class JpegTop:
         self._check(self.lib.jpegenc_set_pipeline(self._ctx, int(mode)))
 
     def region_stats(self):
-        """(groups with a block too long for a small region, ... for a large region, groups) of the last launch
-        that collected them."""
-        c = (C.c_uint64 * 3)()
+        """(groups with a block too long for a small region, ... for a large region, groups, groups with a block too
+        long for a short region) of the last launch that collected them, and the size REGIONS_AUTO stands at."""
+        c = (C.c_uint64 * 5)()
         self._check(self.lib.jpegenc_region_stats(self._ctx, c))
-        return int(c[0]), int(c[1]), int(c[2])
+        return int(c[0]), int(c[1]), int(c[2]), int(c[3]), int(c[4])
 
     def reserve(self, n_images, w, h):
         """Grows the workspace now, so that device-pointer calls of up to this size only enqueue work."""

@@ -92,8 +92,9 @@ def test_header_constants_match_the_python_mirror():
            (pkg.E_LIMIT, pkg.E_NOMEM, pkg.E_STATE)
     assert (int(defs["JPEGENC_PIPELINE_AUTO"]), int(defs["JPEGENC_PIPELINE_SPLIT"]), int(defs["JPEGENC_PIPELINE_SINGLE_MCU"])) == \
            (pkg.JpegTop.PIPELINE_AUTO, pkg.JpegTop.PIPELINE_SPLIT, pkg.JpegTop.PIPELINE_SINGLE_MCU)
-    assert (int(defs["JPEGENC_REGIONS_AUTO"]), int(defs["JPEGENC_REGIONS_SMALL"]), int(defs["JPEGENC_REGIONS_LARGE"])) == \
-           (pkg.JpegTop.REGIONS_AUTO, pkg.JpegTop.REGIONS_SMALL, pkg.JpegTop.REGIONS_LARGE)
+    assert (int(defs["JPEGENC_REGIONS_AUTO"]), int(defs["JPEGENC_REGIONS_SMALL"]), int(defs["JPEGENC_REGIONS_LARGE"]),
+            int(defs["JPEGENC_REGIONS_SHORT"])) == \
+           (pkg.JpegTop.REGIONS_AUTO, pkg.JpegTop.REGIONS_SMALL, pkg.JpegTop.REGIONS_LARGE, pkg.JpegTop.REGIONS_SHORT)
     assert (int(defs["JPEGENC_DEVICE_PTRS"]), int(defs["JPEGENC_PAD_EDGES"]), int(defs["JPEGENC_SEG_CONTINUES"])) == \
            (pkg.DEVICE_PTRS, pkg.PAD_EDGES, pkg.SEG_CONTINUES)
 

@@ -310,12 +310,13 @@ def test_segment_state_is_dropped_by_other_calls_and_one_chunk_last_band():
 
 
 def test_region_modes_give_the_same_stream():
-    """The encode kernel exists with small and with large LDS staging regions (and a third size in the
-    single-launch form); the context picks small or large per launch from the overflow counts of the launches
-    before.  Whatever runs, the words are the oracle's: easy, mixed (every other MCU row noise) and noise content
-    under both forced sizes and in the single-launch form, and a run in automatic mode that starts on easy
-    content, meets the others (switches to large regions) and returns to easy content.  The overflow counts the
-    choice rests on are checked too: none on easy content, every chunk on noise."""
+    """The encode kernel exists with short, small and large LDS staging regions (and a fourth size in the
+    single-launch form); the context picks one per launch from the overflow counts of the launches before.
+    Whatever runs, the words are the oracle's: easy, mixed (every other MCU row noise) and noise content
+    under the three forced sizes and in the single-launch form, and a run in automatic mode that starts on easy
+    content (and moves to short regions if no block of it is too long for them), meets the others (leaves short
+    regions at once, switches to large ones) and returns to easy content.  The overflow counts the choice rests on
+    are checked too: none on easy content, every chunk on noise."""
     pkg = load_pkg()
     dev = torch.device("cuda:0")
     h, w, n = 256, 1024, 36  # 36 x 64 chunks per call: beyond what the single-launch form takes
@@ -345,15 +346,20 @@ def test_region_modes_give_the_same_stream():
             assert np.array_equal(d_words[i, :k].cpu().numpy().view(np.uint32), want[name][i]), (name, i)
 
     contents = (("easy", easy), ("mixed", mixed), ("noise", noise))
-    for mode in (pkg.JpegTop.REGIONS_SMALL, pkg.JpegTop.REGIONS_LARGE):
+    J = pkg.JpegTop
+    easy_over_short = None
+    for mode in (J.REGIONS_SMALL, J.REGIONS_LARGE, J.REGIONS_SHORT):
         with pkg.JpegTop(stream=torch.cuda.current_stream().cuda_stream) as e:
             e.set_region_mode(mode)
             for name, frames in contents:
                 run(e, name, frames)
-                over_small, over_large, total = e.region_stats()
-                assert total == n * 64 and over_large <= over_small <= total
+                over_small, over_large, total, over_short, stands_at = e.region_stats()
+                assert total == n * 64 and over_large <= over_small <= over_short <= total
+                assert stands_at == mode
                 if name == "easy":
                     assert over_small == 0
+                    assert easy_over_short in (None, over_short)  # the same count whichever variant counted
+                    easy_over_short = over_short
                 if name == "noise":
                     assert over_small == total
             e.set_pipeline(pkg.JpegTop.PIPELINE_SPLIT)  # a small call as separate kernels takes the forced size too
@@ -363,8 +369,18 @@ def test_region_modes_give_the_same_stream():
         for name, frames in contents:
             run(e, name, frames, 30)
     with pkg.JpegTop(stream=torch.cuda.current_stream().cuda_stream) as e:  # automatic
-        for name, frames in (contents[0], contents[1], contents[1], contents[1], contents[2], contents[2], contents[0],
-                             contents[0], contents[0]):
+        assert e.region_stats()[4] == J.REGIONS_SMALL
+        for _ in range(6):
+            run(e, "easy", easy)
+        if easy_over_short * 1024 < n * 64:  # four launches' counts in favour: short regions from the fifth on
+            assert e.region_stats()[4] == J.REGIONS_SHORT
+        run(e, "mixed", mixed)  # (coded with whatever the easy launches left; its counts arrive behind it)
+        run(e, "mixed", mixed)
+        assert e.region_stats()[4] != J.REGIONS_SHORT
+        for name, frames in (contents[1], contents[2], contents[2]):
+            run(e, name, frames)
+        assert e.region_stats()[4] == J.REGIONS_LARGE
+        for name, frames in (contents[0], contents[0], contents[0]):
             run(e, name, frames)
 
 

@@ -72,7 +72,7 @@ def test_noalloc_entry_point_matches_the_allocating_one():
         assert (r_ref["status"] == 0).all() and r_new.tobytes() == r_ref.tobytes() and np.array_equal(w_new, w_ref)
 
 
-@pytest.mark.parametrize("mode", ["auto", "small", "large", "quant"])
+@pytest.mark.parametrize("mode", ["auto", "small", "large", "short", "quant"])
 def test_noalloc_call_replays_from_a_captured_graph(mode):
     """The call captured once on a side stream, then replayed three times on other pixels in the same buffers:
     every replay gives the oracle's words (nothing in the launches is tied to the call that was captured).  With
@@ -95,8 +95,8 @@ def test_noalloc_call_replays_from_a_captured_graph(mode):
     qtabs = [[3 + (i % 7) for i in range(64)]] * 3 if mode == "quant" else None
     cfg = O.default_config(qtabs=qtabs)
     with pkg.JpegTop(stream=side.cuda_stream, qtabs=qtabs) as e:
-        if mode in ("small", "large"):
-            e.set_region_mode(e.REGIONS_SMALL if mode == "small" else e.REGIONS_LARGE)
+        if mode in ("small", "large", "short"):
+            e.set_region_mode({"small": e.REGIONS_SMALL, "large": e.REGIONS_LARGE, "short": e.REGIONS_SHORT}[mode])
         e.encode_batch_noalloc(*args)  # once outside capture: code objects loaded, nothing left to set up
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()

@@ -57,7 +57,7 @@ def main():
         with pkg.JpegTop(**kw) as e:
             # launch structure and LDS region size change the speed only: any combination must give the same words
             e.set_pipeline(int(rng.integers(0, 3)))
-            e.set_region_mode(int(rng.integers(0, 3)))
+            e.set_region_mode(int(rng.integers(0, 4)))
             # chunk slots sized from the calls before (host-pointer calls repeat themselves when a chunk outgrows them)
             e.set_slot_mode(int(rng.integers(0, 2)))
             for _ in range(4):
