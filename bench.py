@@ -29,7 +29,8 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=5,
+                    help="untimed steps (the library settles its LDS region size after five calls: see jpegenc_set_region_mode)")
     ap.add_argument("--frames", type=int, default=1024, help="frames per GPU (weak scaling)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--total-frames", type=int, default=8192, help="frames of the whole job (strong scaling)")
