@@ -327,6 +327,8 @@ def test_region_modes_give_the_same_stream():
     mixed = easy.clone()
     mixed[:, 8::16] = noise[:, 8::16]  # rows 8, 24, ...: one pixel row of noise in every other MCU row
     mixed[:, 12::16] = noise[:, 12::16]
+    # pixels of 0 and 255 only: the longest codes pixels can give, four to five lane ranges per chunk with short regions
+    binary = (torch.randint(0, 2, (n, h, w, 3), generator=g, device=dev, dtype=torch.uint8) * 255).contiguous()
     cap = pkg.max_words(w, h)
     want = {}
 
@@ -362,6 +364,8 @@ def test_region_modes_give_the_same_stream():
                     easy_over_short = over_short
                 if name == "noise":
                     assert over_small == total
+            run(e, "binary", binary)
+            assert e.region_stats()[1] > 0  # (some blocks are too long even for a large region)
             e.set_pipeline(pkg.JpegTop.PIPELINE_SPLIT)  # a small call as separate kernels takes the forced size too
             for name, frames in contents:
                 run(e, name, frames, 3)
