@@ -373,7 +373,7 @@ int workspace_used(jpegenc_ctx* ctx) {
 
 // Region size for the next launch of the encode kernel, and its statistics buffer (zeroed on the stream, together
 // with the images' flag words when the slots are not the worst case).  Only the common kernel variant (8-byte-aligned
-// rows, all-ones tables) exists with large regions.
+// rows, all-ones tables) exists with large and with short regions.
 int choose_regions(jpegenc_ctx* ctx, EncodeParams* ep, int align, uint64_t chunks, uint32_t n_images) {
     ep->stats = nullptr;
     ep->regions = kRegionsSmall;
@@ -419,14 +419,14 @@ int choose_regions(jpegenc_ctx* ctx, EncodeParams* ep, int align, uint64_t chunk
                     ctx->small_votes = ctx->short_votes = 0;
                 }
             } else if (ctx->regions == kRegionsShort) {
-                // Short regions gain 1 % and lose 15 % with 6 % of the chunks redone: they are left as soon as one
-                // chunk in 256 holds an MCU too long for them ...
+                // Short regions gain 1 to 2.4 % and lose 15 % with 6 % of the chunks redone: they are left as soon as
+                // one chunk in 256 holds an MCU too long for them ...
                 if (over_short * 256 > total) {
                     ctx->regions = kRegionsSmall;
                     ctx->short_votes = 0;
                 }
             } else {
-                // ... and taken after four launches in a row with fewer than one in 1024
+                // ... and taken after four calls in a row that find fewer than one in 1024 in the latest counts
                 ctx->short_votes = over_short * 1024 < total ? ctx->short_votes + 1 : 0;
                 if (ctx->short_votes >= 4) {
                     ctx->regions = kRegionsShort;
