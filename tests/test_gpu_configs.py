@@ -373,6 +373,9 @@ def test_region_modes_give_the_same_stream():
         for name, frames in contents:
             run(e, name, frames, 30)
     with pkg.JpegTop(stream=torch.cuda.current_stream().cuda_stream) as e:  # automatic
+        for bad in (-1, 4):
+            with pytest.raises(pkg.JpegEncError):
+                e.set_region_mode(bad)
         assert e.region_stats()[4] == J.REGIONS_SMALL
         for _ in range(6):
             run(e, "easy", easy)
